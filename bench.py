@@ -2,24 +2,37 @@
 """Headline benchmark: node-pairs/s on the N x N structural-distance matrix (BASELINE.json).
 
     python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node P ... bench.py --gpus P --steps K --warmup W
 
-Workload (config.workload): BASELINE.json configs[1] -- synthetic Erdos-Renyi N=10 000 p=0.001,
-K=3, Wasserstein on per-hop degree signatures, on one MI355X.  Primary = Variant B, the distance
-main.py:26 computes (HSD.parallel_calculate_HSD -> tools.metrics.calculate_distance: zero-pad
-alignment, layers 0..K-1); Variant A (HSD.calculate_structural_distance: scipy on the raw ragged
-samples, layers 0..K) is measured in the same run and reported under "secondary" (--variant A swaps them).  A "step" is one pass of the
-all-pairs kernel over the whole (row block of the) distance matrix with the signature operands
-already resident in HBM.  With --gpus P > 1 the same per-GPU work is kept (weak scaling):
-N = 10 000 * sqrt(P) nodes at mean degree 10, the pair space row-block partitioned after ONE
-RCCL all-gather of the histogram tensor (not inside the timed region; reported separately).
+Headline workload (config.workload) = the north-star target, SURVEY.md 8(d) "target": synthetic
+Barabasi-Albert N = 100 000, m = 5, seed 42, K = 3, Wasserstein on per-hop degree signatures, the full
+symmetric fp64 matrix (80 GB) resident in HBM.  It is the largest single-GPU configuration BASELINE.json
+names, and the one its roofline target is quoted on.
 
-The line printed by rank 0 carries, next to the contract keys,
-  roofline      HBM roofline of the all-pairs kernel from HIP-event timing of the K launches
-  cpu_baseline  the reference's own loop (model/HSD.py:103-112: scipy.stats.wasserstein_distance
-                per layer per pair) timed on this host on the first rows of the same matrix, and
-                used as the parity sample for the GPU result
-  secondary     the other alignment variant measured in the same run
+  primary    Variant A -- HSD.calculate_structural_distance (model/HSD.py:98-114): scipy
+             wasserstein_distance on the raw ragged ring samples, layers 0..K, fp64
+  secondary  Variant B -- HSD.parallel_calculate_HSD, the call main.py:26 makes (model/HSD.py:140-161):
+             tools.metrics.calculate_distance = zero-pad alignment + scipy, layers 0..K-1, exact integers
+
+A "step" is one pass of the all-pairs kernel over the whole matrix (this rank's row block of it) with
+the signature operands already resident in HBM.  With --gpus P > 1 the SAME matrix is row-block
+partitioned over the ranks ("scaling": "strong"; SURVEY 8(e), model/HSD.py:118-137 is the pool it
+replaces) after ONE RCCL all-gather of the histogram tensor (outside the timed region, reported under
+phases_s); at P = 8 BASELINE's config 4 (N = 200 000) is run the same way and reported under "configs".
+--weak keeps round 1's weak-scaling mode (ER N = 10 000 sqrt(P)).
+
+On one GPU the line also carries, under "configs", BASELINE.json's other single-GPU configurations
+measured in the same run with the same keys (roofline, cpu_baseline, parity):
+  config 2  ER N = 10 000 p = 0.001, K = 3, Wasserstein (both variants + the heat-coefficient path)
+  config 3  BA N = 50 000 m = 5, K = 5, KL divergence
+  config 5  MultiHSD heat-kernel signatures, 8 scales, BA N = 50 000, K = 3
+
+Keys next to the contract's:
+  roofline      HBM roofline of the all-pairs kernel from HIP-event timing of the K launches on the stream
+                they run on; valu_frac = the same launches priced against the vector-ALU issue rate (these
+                kernels are arithmetic-bound beyond a few dozen operand columns)
+  cpu_baseline  the reference's own loop (scipy.stats.wasserstein_distance per layer per pair) timed on this
+                host on a bounded sample of pairs of the same matrix; the same pairs are the parity sample
 """
 import argparse
 import json
@@ -34,32 +47,199 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK = 39.3e12       # fp64 vector instructions/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (78.6 TFLOP/s FMA)
-U32_VALU_PEAK = 78.6e12        # 32-bit vector instructions/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+# Vector-ALU issue peaks in lane-instructions/s.  fp64 add/fma and the 3-operand integer SADs (v_sad_u32 / v_sad_u16)
+# all issue at 16 lanes per clock per SIMD on gfx950 (measured: 4.1 cycles per wave-instruction, tools_dev/ubench_valu.hip,
+# profiles/r02_ubench_valu.txt): 256 CU x 4 SIMD x 16 lanes x 2.4 GHz.
+FP64_VALU_PEAK = 39.3e12
+SAD_VALU_PEAK = 39.3e12
+
+WORKLOADS = {
+    "target": dict(graph="ba", nodes=100000, m=5, hop=3, metric="wasserstein",
+                   name="north-star target (SURVEY 8(d)): barabasi_albert N=100000 m=5 seed=42, K=3, Wasserstein"),
+    "config2": dict(graph="er", nodes=10000, p=0.001, hop=3, metric="wasserstein",
+                    name="BASELINE configs[1]: erdos_renyi N=10000 p=0.001 seed=42, K=3, Wasserstein"),
+    "config3": dict(graph="ba", nodes=50000, m=5, hop=5, metric="kl",
+                    name="BASELINE configs[2]: barabasi_albert N=50000 m=5 seed=42, K=5, KL divergence"),
+    "config4": dict(graph="ba", nodes=200000, m=5, hop=3, metric="wasserstein",
+                    name="BASELINE configs[3]: scale-free (barabasi_albert m=5 seed=42) N=200000, K=3, Wasserstein, row blocks"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--nodes", type=int, default=10000, help="nodes per sqrt(GPU) (configs[1]: 10000)")
-    ap.add_argument("--mean-degree", type=float, default=10.0, help="N*p (configs[1]: 10000*0.001)")
-    ap.add_argument("--graph", default="er", choices=["er", "ba"])
-    ap.add_argument("--hop", type=int, default=3)
-    ap.add_argument("--variant", default="B", choices=["A", "B"],
-                    help="A: scipy on raw ring samples, layers 0..K (model/HSD.py:98-114); "
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", default="A", choices=["A", "B"],
+                    help="primary variant. A: scipy on raw ring samples, layers 0..K (model/HSD.py:98-114); "
                          "B: tools.metrics.calculate_distance zero-pad alignment, layers 0..K-1 (model/HSD.py:140-161)")
-    ap.add_argument("--metric", default="wasserstein", choices=["wasserstein", "kl", "symmetric_kl"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the scipy baseline sample (0 = skip)")
+    ap.add_argument("--configs", default=None,
+                    help="comma list of the other BASELINE configs measured beside the headline (2,3,5 on one GPU; 4 on "
+                         "eight); 'none' to skip.  Default: 2,3,5 at --gpus 1, 4 at --gpus 8, none otherwise")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the scipy baseline sample of the headline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--weak", action="store_true", help="round-1 weak-scaling mode: ER N = nodes * sqrt(P), per-GPU output fixed")
+    # overrides (measurement scripts): a custom graph instead of a named workload
+    ap.add_argument("--graph", default=None, choices=["er", "ba"])
+    ap.add_argument("--nodes", type=int, default=None)
+    ap.add_argument("--mean-degree", type=float, default=10.0)
+    ap.add_argument("--hop", type=int, default=None)
+    ap.add_argument("--metric", default=None, choices=["wasserstein", "kl", "symmetric_kl"])
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def make_graph(spec):
+    import hsd_amd
+    n = spec["nodes"]
+    if spec["graph"] == "er":
+        p = spec.get("p", spec.get("mean_degree", 10.0) / n)
+        g = hsd_amd.erdos_renyi(n, p, seed=42)
+        if spec.get("connect"):
+            # a scaled-up G(n, 10/n) has ~n e^-10 isolated nodes; their empty rings make scipy (and Variant A)
+            # raise, so small components are tied to the giant one by one edge each
+            from hsd_amd.graph import connect_components
+            g = connect_components(g, seed=42)
+        return g
+    return hsd_amd.barabasi_albert(n, spec.get("m", 5), seed=42)
 
 
 def variant_params(variant, hop):
     return (0, 0, hop) if variant == "A" else (1, 0, hop - 1)      # (align, layer_lo, layer_hi)
 
 
+def variant_call(variant):
+    return ("HSD.calculate_structural_distance (model/HSD.py:98-114): scipy on raw ring samples" if variant == "A" else
+            "HSD.parallel_calculate_HSD, the call main.py:26 makes (model/HSD.py:140-161): zero-pad alignment")
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def sample_nodes(n, count, seed=7):
+    """Nodes the CPU baseline / parity sample is taken on: spread over the whole node order (the first rows of a
+    preferential-attachment graph are its hubs -- not a representative sample)."""
+    rng = np.random.default_rng(seed)
+    return np.sort(rng.choice(n, size=min(count, n), replace=False)).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's loop on the same signatures, on a bounded sample of pairs
+# ------------------------------------------------------------------------------------------------
+def _pair_scipy(nr, a, b, align, lo, hi, wd):
+    d = 0.0
+    for k in range(lo, hi + 1):
+        p, q = nr.sample(a, k), nr.sample(b, k)
+        if align:                                   # tools/metrics.py:18-36: zero-pad the shorter list, sort both
+            L = max(len(p), len(q))
+            if L == 0:
+                continue                            # tools/metrics.py:170-171: both empty -> 0.0
+            p = np.sort(np.concatenate([p, np.zeros(L - len(p))]))
+            q = np.sort(np.concatenate([q, np.zeros(L - len(q))]))
+        d += wd(p, q)
+    return d
+
+
+def scipy_baseline(g, hop, variant, budget_s, n_sample=400):
+    """for i, for j > i over a sample of nodes: sum over layers of scipy.stats.wasserstein_distance (Variant A,
+    model/HSD.py:103-112) or tools.metrics.calculate_distance's zero-pad + scipy (Variant B, tools/metrics.py:18-36,
+    186-190).  Returns dict(rate, pairs, seconds, sample {(i, j): d}, nodes)."""
+    from scipy.stats import wasserstein_distance
+    from oracle import c_oracle as corc
+    nodes = sample_nodes(g.n_node, n_sample)
+    nr = corc.NodeRingSamples(g.rowptr, g.col, hop, g.degree.astype(np.float64), nodes)
+    align, lo, hi = variant_params(variant, hop)
+    sample = {}
+    t0 = time.perf_counter()
+    done = False
+    # anti-diagonal order over the sampled nodes, so that a run cut short still mixes early and late nodes
+    m = len(nodes)
+    for s in range(1, 2 * m):
+        for ia in range(max(0, s - m + 1), (s + 1) // 2):
+            ib = s - ia
+            if ib >= m or ia >= ib:
+                continue
+            a, b = int(nodes[ia]), int(nodes[ib])
+            sample[(a, b)] = _pair_scipy(nr, a, b, align, lo, hi, wasserstein_distance)
+            if len(sample) % 64 == 0 and time.perf_counter() - t0 > budget_s:
+                done = True
+                break
+        if done:
+            break
+    dt = time.perf_counter() - t0
+    return dict(rate=len(sample) / dt, pairs=len(sample), seconds=dt, sample=sample, nodes=nodes)
+
+
+_POOL = {}
+
+
+def _pool_init(rowptr, col, hop, degree, nodes, variant):
+    from oracle import c_oracle as corc
+    _POOL["nr"] = corc.NodeRingSamples(rowptr, col, hop, degree, nodes)
+    _POOL["nodes"], _POOL["variant"], _POOL["hop"] = nodes, variant, hop
+
+
+def _pool_row(task):
+    """One task per source row, as model/HSD.py:122-124 submits them: sampled node ia against the later sampled nodes."""
+    from scipy.stats import wasserstein_distance
+    ia, count = task
+    nr, nodes = _POOL["nr"], _POOL["nodes"]
+    align, lo, hi = variant_params(_POOL["variant"], _POOL["hop"])
+    done = 0
+    for ib in range(ia + 1, min(len(nodes), ia + 1 + count)):
+        _pair_scipy(nr, int(nodes[ia]), int(nodes[ib]), align, lo, hi, wasserstein_distance)
+        done += 1
+    return done
+
+
+def scipy_pool_baseline(g, hop, variant, budget_s, single_rate):
+    """The same loop fanned out over a process pool of os.cpu_count() workers, one task per source row
+    (model/HSD.py:118-130), sized from the single-core rate to last about budget_s."""
+    import multiprocessing as mp
+    workers = min(os.cpu_count() or 1, 64)
+    per_task = max(16, int(single_rate * budget_s / 4))            # ~4 tasks per worker
+    n_tasks = workers * 4
+    nodes = sample_nodes(g.n_node, min(g.n_node, n_tasks + per_task + 1), seed=11)
+    tasks = [(i, per_task) for i in range(min(n_tasks, len(nodes) - 1))]
+    ctx = mp.get_context("fork")
+    with ctx.Pool(workers, initializer=_pool_init,
+                  initargs=(g.rowptr, g.col, hop, g.degree.astype(np.float64), nodes, variant)) as pool:
+        t0 = time.perf_counter()
+        done = sum(pool.map(_pool_row, tasks, chunksize=1))
+        dt = time.perf_counter() - t0
+    return dict(rate=done / dt, pairs=done, workers=workers, seconds=dt)
+
+
+def parity_against(mat, r0, sample, tol=1e-6):
+    """GPU matrix entries against the CPU sample {(i, j): d}: rows are fetched once each."""
+    rows = {}
+    worst = 0.0
+    checked = 0
+    r1 = r0 + mat.rows
+    for (i, j), d in sample.items():
+        if not (r0 <= i < r1):
+            continue
+        if i not in rows:
+            rows[i] = mat.rows_to_host(i - r0, i - r0 + 1)[0]
+        worst = max(worst, abs(rows[i][j] - d) / max(abs(d), 1e-12))
+        checked += 1
+    return dict(pairs_checked=checked, max_rel_err=worst, tol=tol, ok=bool(checked > 0 and worst <= tol))
+
+
+# ------------------------------------------------------------------------------------------------
+# timing + roofline of the all-pairs kernel
+# ------------------------------------------------------------------------------------------------
 def time_pair(eng, mat, r0, r1, steps, warmup, barrier):
     for _ in range(warmup):
         eng.pair_rows_device(r0, r1, mat)
@@ -76,103 +256,352 @@ def time_pair(eng, mat, r0, r1, steps, warmup, barrier):
     return wall, ev_ms
 
 
-def scipy_baseline(g, hop, variant, budget_s):
-    """The reference's loop on the same signatures: for i, for j > i, sum over layers of
-    scipy.stats.wasserstein_distance (Variant A, model/HSD.py:103-112) or
-    tools.metrics.calculate_distance's zero-pad + scipy (Variant B, tools/metrics.py:18-36,186-190).
-    Returns (pairs/s, pairs evaluated, rows, {(i, j): d} sample for the parity check)."""
-    from scipy.stats import wasserstein_distance
-    from oracle import c_oracle as corc
-    rs = corc.RingSamples(g.rowptr, g.col, hop, g.degree.astype(np.float64))
-    n = g.n_node
-    align, lo, hi = variant_params(variant, hop)
-    sample = {}
-    pairs = 0
+def load_traffic(key):
+    """HBM bytes per launch from the PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected in
+    their own runs as MI355X_MICROARCH.md prescribes; summaries under profiles/).  None if that workload was not profiled."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                t = json.load(f).get(key)
+            if t is not None:
+                return dict(t, source=f"profiles/{name}") if isinstance(t, dict) else t
+        except OSError:
+            pass
+    return None
+
+
+def kernel_roofline(n, rows, res, steps, metric, traffic_key=None):
+    """bytes_alg = 8 * rows * N (each fp64 output written once) + operand matrix read once; beside it
+    the vector instructions the launch needs at minimum (fp64 W1: 2 per column pair, integer SAD: 1 per word pair,
+    KL: 1 FMA) against the issue peak."""
+    bytes_alg = 8.0 * rows * n + float(res["ebytes"]) * n * res["cols"]
+    t_kernel = res["ev_ms"] * 1e-3 / steps
+    achieved = bytes_alg / t_kernel / 1e9
+    sq = rows * (rows + 1) / 2.0 + rows * (n - rows)            # pairs this rank evaluates (diagonal square once)
+    if res["ebytes"] == 4:
+        instr, peak = sq * res["cols"] * (3.0 if res["align"] == 0 else 1.0), SAD_VALU_PEAK
+    else:
+        instr, peak = sq * res["cols"] * (2.0 if metric == "wasserstein" else 1.0), FP64_VALU_PEAK
+    return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=load_traffic(traffic_key) if traffic_key else None,
+                kernel_ms=round(t_kernel * 1e3, 4), bytes_alg=bytes_alg,
+                valu_frac=round(instr / t_kernel / peak, 4), valu_peak_lane_instr_per_s=peak,
+                limiter="vector ALU issue" if instr / peak > bytes_alg / (HBM_PEAK_GBS * 1e9) else "HBM write stream",
+                operand_columns=res["cols"])
+
+
+def dtype_of(res, n_bins):
+    """Arithmetic type of the kernel: fp64, uint32 SAD, or two uint16 columns per 32-bit word (v_sad_u16)."""
+    if res["ebytes"] != 4:
+        return "f64"
+    point = 1 if res["lo"] == 0 else 0
+    packed = (res["cols"] - point) < (res["hi"] - res["lo"] + 1 - point) * n_bins
+    return "u16" if packed else "u32"
+
+
+class Ranks:
+    """Control plane of a multi-rank run (gloo): barriers, max over ranks, error agreement."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def gather(self, x):
+        if self.dist is None:
+            return [x]
+        import torch
+        t = torch.zeros(self.world, dtype=torch.float64)
+        t[self.rank] = x
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    def any(self, flag):
+        return bool(self.max(1.0 if flag else 0.0))
+
+
+def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, traffic_prefix=None, dryrun=False):
+    """k-hop sweep + histograms (this rank's sources), the exchange, then every variant: prepare, first call, timed
+    steps.  Returns dict(variants={name: result}, phases, sweep, n_bins)."""
+    from hsd_amd import _lib as L
+    from hsd_amd import distributed as hdist
+    n, hop, metric = g.n_node, spec["hop"], spec["metric"]
     t0 = time.perf_counter()
-    i = 0
-    while i < n - 1:
-        si = [rs.sample(i, k) for k in range(lo, hi + 1)]
-        for j in range(i + 1, n):
-            d = 0.0
-            for kk, k in enumerate(range(lo, hi + 1)):
-                p, q = si[kk], rs.sample(j, k)
-                if align:
-                    L = max(len(p), len(q))
-                    if L == 0:
-                        continue
-                    p = np.sort(np.concatenate([p, np.zeros(L - len(p))]))
-                    q = np.sort(np.concatenate([q, np.zeros(L - len(q))]))
-                d += wasserstein_distance(p, q)
-            sample[(i, j)] = d
-            pairs += 1
-            if pairs % 256 == 0 and time.perf_counter() - t0 > budget_s:
-                break
-        i += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return pairs / dt, pairs, i, sample, dt
+    eng.set_graph(g.rowptr, g.col)
+    eng.sync()
+    t_graph = time.perf_counter() - t0
+    r0, r1 = hdist.init_comm(eng, rk.dist, rk.rank, rk.world) if rk.world > 1 else (0, n)
+    assert (r0, r1) == hdist.shard_rows(n, rk.world, rk.rank)
+    eng.sync()
+    t0 = time.perf_counter()
+    eng.signature_build_degree(hop, r0, r1)
+    eng.sync()
+    t_sig = time.perf_counter() - t0
+    # the sweep once more under the device stopwatch (buffers exist now), with its algorithmic bytes (SURVEY 8(d)):
+    # sum over sources of sum_{v in ball_{K-1}} (8 + 4 deg v)  +  the histogram rows written
+    eng.timer_start()
+    eng.signature_build_degree(hop, r0, r1)
+    sweep_ms = eng.timer_stop()
+    sweep = None
+    n_bins = int(eng.signature_dims()[1])
+    if rk.rank == 0 and r1 > r0:
+        sizes = eng.khop_sizes(hop, r0, min(r1, r0 + 2000))                # sample of sources for the ball sizes
+        inner = float(sizes[:, :hop].sum(axis=1).mean())                   # |ball_{K-1}| per source
+        bytes_sweep = (r1 - r0) * inner * (8.0 + 4.0 * float(g.degree.mean())) + 4.0 * (r1 - r0) * (hop + 1) * n_bins
+        sweep = {"kernel": "khop_kernel (k-hop sweep + per-hop histograms)", "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
+                 "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
+                 "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "bound": "LDS atomics / latency (the graph is L2-resident), not HBM"}
+    t0 = time.perf_counter()
+    hdist.allgather_signature(eng, rk.dist, rk.rank, rk.world, via="host" if dryrun else "rccl")   # ONE ncclAllGather over xGMI
+    eng.sync()
+    t_gather = time.perf_counter() - t0
+
+    metric_code = {"wasserstein": L.METRIC_WASSERSTEIN, "kl": L.METRIC_KL, "symmetric_kl": L.METRIC_SYMMETRIC_KL}[metric]
+    out = {}
+    for variant in variants:
+        align, lo, hi = variant_params(variant, hop) if metric == "wasserstein" else (0, 0, hop)
+        err, res, mat = None, None, None
+        try:
+            t0 = time.perf_counter()
+            eng.pair_prepare(metric_code, align, lo, hi, 0.5, False)
+            eng.sync()
+            t_prep = time.perf_counter() - t0
+            cols, ebytes = eng.pair_operand_dims()
+            t0 = time.perf_counter()
+            mat = eng.pair_rows_device(r0, r1)          # allocates this rank's row block (80 GB at N = 100k) and fills it
+            eng.sync()
+            t_first = time.perf_counter() - t0
+            # a second prepare + matrix into the existing block: what one more distance matrix costs once the
+            # context is warm (buffers, code objects, tile lists exist)
+            t0 = time.perf_counter()
+            eng.pair_prepare(metric_code, align, lo, hi, 0.5, False)
+            eng.pair_rows_device(r0, r1, mat)
+            eng.sync()
+            t_warm = time.perf_counter() - t0
+        except ValueError as e:             # Variant A raises on an empty ring, as scipy does
+            err = e
+        # an exception on SOME ranks must not leave the others waiting in the barriers of the timed loop
+        if rk.any(err is not None):
+            if mat is not None:
+                mat.free()
+            out[variant] = dict(variant=variant, error=str(err) if err else "Distribution can't be empty. (raised on another rank)")
+            continue
+        wall, ev_ms = time_pair(eng, mat, r0, r1, steps, warmup, rk.barrier)
+        res = dict(variant=variant, wall=rk.max(wall), wall_rank=wall, ev_ms=ev_ms, cols=cols, ebytes=ebytes, align=align, lo=lo, hi=hi,
+                   t_prep=t_prep, t_first=t_first, t_warm=t_warm, rows=(r0, r1))
+        key = f"{traffic_prefix}_{variant}" if traffic_prefix and rk.world == 1 else None
+        res["roofline"] = kernel_roofline(n, r1 - r0, res, steps, metric, key)
+        res["pairs_per_s"] = n * (n - 1) / 2.0 * steps / res["wall"]
+        res["ms_per_step"] = res["wall"] * 1e3 / steps
+        res["dtype"] = dtype_of(res, n_bins)
+        res["kernel_ms_per_rank"] = [round(v, 4) for v in rk.gather(ev_ms / steps)]
+        if cpu and variant in cpu:
+            res["parity"] = parity_against(mat, r0, cpu[variant]["sample"])
+        st = mat.stats()
+        res["matrix_check"] = {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")}
+        mat.free()
+        out[variant] = res
+    return dict(variants=out, sweep=sweep, n_bins=n_bins, rows=(r0, r1),
+                phases=dict(set_graph=round(t_graph, 4), khop_signature_build=round(t_sig, 4), allgather=round(t_gather, 4)))
 
 
-_POOL = {}
+def cpu_entry(c, variant, hop, what):
+    loop = ("model/HSD.py:140-161 (_calculate_worker): tools.metrics.calculate_distance = zero-pad + sort + "
+            "scipy.stats.wasserstein_distance per layer" if variant == "B" else
+            "model/HSD.py:103-112 calling scipy.stats.wasserstein_distance per layer")
+    return dict(value=round(c["rate"], 1), unit="node-pairs/s", cores=1, kind="port",
+                sample=f"{c['pairs']} pairs among {len(c['nodes'])} nodes spread over the node order of {what}, {c['seconds']:.1f} s; "
+                       f"loop of {loop} on the same degree signatures (variant {variant}); host: {cpu_model()}, {os.cpu_count()} cores")
 
 
-def _pool_init(rowptr, col, hop, degree, variant):
-    from oracle import c_oracle as corc
-    _POOL["rs"] = corc.RingSamples(rowptr, col, hop, degree)
-    _POOL["variant"], _POOL["hop"] = variant, hop
+def variant_summary(res):
+    if "error" in res:
+        return dict(variant=res["variant"], error=res["error"])
+    return dict(variant=res["variant"], call=variant_call(res["variant"]), value=res["pairs_per_s"], unit="node-pairs/s",
+                ms_per_step=res["ms_per_step"], dtype=res["dtype"], roofline=res["roofline"], parity=res.get("parity"),
+                phases_s=dict(operand_prepare_first=round(res["t_prep"], 4), first_matrix_incl_allocation=round(res["t_first"], 4),
+                              warm_prepare_plus_matrix=round(res["t_warm"], 4)),
+                matrix_check=res["matrix_check"])
 
 
-def _pool_row(task):
-    """One task per source row, as model/HSD.py:122-124 submits them: row i against `count` later rows."""
-    from scipy.stats import wasserstein_distance
-    i, count = task
-    rs, variant, hop = _POOL["rs"], _POOL["variant"], _POOL["hop"]
-    align, lo, hi = variant_params(variant, hop)
-    si = [rs.sample(i, k) for k in range(lo, hi + 1)]
-    done = 0
-    for j in range(i + 1, min(rs.n, i + 1 + count)):
-        d = 0.0
-        for kk, k in enumerate(range(lo, hi + 1)):
-            p, q = si[kk], rs.sample(j, k)
-            if align:
-                L = max(len(p), len(q))
-                if L == 0:
-                    continue
-                p = np.sort(np.concatenate([p, np.zeros(L - len(p))]))
-                q = np.sort(np.concatenate([q, np.zeros(L - len(q))]))
-            d += wasserstein_distance(p, q)
-        done += 1
-    return done
+# ------------------------------------------------------------------------------------------------
+# the other BASELINE configs (one GPU)
+# ------------------------------------------------------------------------------------------------
+def heat_path(eng, g, hop):
+    """The reference's own signature (heat coefficients, model/HSD.py:48-114) on the same graph: psi by the Chebyshev
+    kernel, ragged sorted samples, all-pairs scipy-semantics W1.  Dense psi, so only while N^2 doubles is small."""
+    import hsd_amd
+    n = g.n_node
 
-
-def scipy_pool_baseline(g, hop, variant, budget_s, single_rate):
-    """The same loop fanned out over a process pool of os.cpu_count() workers, one task per source
-    row (model/HSD.py:118-130), sized from the single-core rate to last about budget_s."""
-    import multiprocessing as mp
-    workers = min(os.cpu_count() or 1, 64)
-    per_task = max(64, int(single_rate * budget_s / 4))            # ~4 tasks per worker
-    tasks = [(i, per_task) for i in range(workers * 4)]
-    ctx = mp.get_context("fork")
-    with ctx.Pool(workers, initializer=_pool_init,
-                  initargs=(g.rowptr, g.col, hop, g.degree.astype(np.float64), variant)) as pool:
+    def timed(fn):
+        eng.sync()
         t0 = time.perf_counter()
-        done = sum(pool.map(_pool_row, tasks, chunksize=1))
-        dt = time.perf_counter() - t0
-    return done / dt, done, workers, dt
-
-
-def cpu_model():
+        r = fn()
+        eng.sync()
+        return r, time.perf_counter() - t0
     try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
+        hm = hsd_amd.HSD(g, "bench", 1.0, hop, "wasserstein", engine=eng)
+        hm._check_default_hierarchy()
+        psi, t_psi = timed(lambda: hm._wavelets_device(1.0, True))
+        with psi:
+            _, t_samp = timed(lambda: eng.heat_signature_build(hop, psi))
+            DA, _ = timed(lambda: eng.pair_heat_rows_device(0, hop))
+            with DA:
+                _, t_a = timed(lambda: eng.pair_heat_rows_device(0, hop, matrix=DA))
+                _, t_b = timed(lambda: eng.pair_heat_rowform_device(psi, matrix=DA))
+        pairs = n * (n - 1) / 2.0
+        nnzL = g.n_edge * 2 + n
+        cblk = min(n, 1024)
+        steps_total = 50 * math.ceil(n / cblk)
+        bytes_step = 12.0 * nnzL + 24.0 * n * cblk                      # SURVEY 8(d): per order and column block
+        t_step = t_psi / steps_total
+        return {"signature": "heat coefficients psi = exp(-L), Chebyshev order 50, threshold 1e-4/N",
+                "wavelets_s": round(t_psi, 4), "sorted_ring_samples_s": round(t_samp, 4),
+                "variant_A_pair_s": round(t_a, 4), "variant_A_pairs_per_s": pairs / t_a,
+                "variant_B_as_written_pair_s": round(t_b, 4), "variant_B_as_written_pairs_per_s": pairs / t_b,
+                "k4": {"kernel": "cheby_step_kernel (one Chebyshev order of a 1024-impulse block)", "ms": round(t_step * 1e3, 4),
+                       "bytes_alg": bytes_step, "achieved_GBps": round(bytes_step / t_step / 1e9, 1),
+                       "frac_of_hbm": round(bytes_step / t_step / 1e9 / HBM_PEAK_GBS, 4)}}
+    except (ValueError, MemoryError) as e:
+        return {"error": str(e)}
 
 
+def run_config2(eng, rk, steps, warmup, cpu_seconds):
+    spec = WORKLOADS["config2"]
+    g = make_graph(spec)
+    cpu = {v: scipy_baseline(g, spec["hop"], v, cpu_seconds / 2) for v in ("A", "B")} if cpu_seconds > 0 else None
+    r = run_degree_workload(eng, rk, g, spec, ["A", "B"], steps, warmup, cpu=cpu, traffic_prefix="er_n10000_K3")
+    ent = dict(config="configs[1]", workload=spec["name"], nodes=g.n_node, edges=g.n_edge, hop=spec["hop"], bins=r["n_bins"],
+               steps=steps, variants=[variant_summary(r["variants"][v]) for v in ("A", "B")],
+               other_kernels=[r["sweep"]], phases_s=r["phases"])
+    if cpu:
+        ent["cpu_baseline"] = {v: cpu_entry(cpu[v], v, spec["hop"], "this graph") for v in ("A", "B")}
+    ent["heat_signature_path"] = heat_path(eng, g, spec["hop"])
+    return ent
+
+
+def run_config3(eng, rk, steps, warmup, cpu_seconds):
+    """KL on alpha-smoothed per-ring histograms; CPU baseline = the C restatement of
+    tools/metrics.py:74-88 on the same histograms (kind "port": the reference's KL has no runnable semantics on ring
+    samples), timed on a few rows; the same rows are the parity sample."""
+    from oracle import c_oracle as corc
+    spec = WORKLOADS["config3"]
+    g = make_graph(spec)
+    r = run_degree_workload(eng, rk, g, spec, ["KL"], steps, warmup, traffic_prefix="ba_n50000_K5")
+    res = r["variants"]["KL"]
+    ent = dict(config="configs[2]", workload=spec["name"], nodes=g.n_node, edges=g.n_edge, hop=spec["hop"], bins=r["n_bins"], steps=steps,
+               other_kernels=[r["sweep"]], phases_s=r["phases"])
+    if "error" in res:
+        ent["error"] = res["error"]
+        return ent
+    ent.update(value=res["pairs_per_s"], unit="node-pairs/s", ms_per_step=res["ms_per_step"], dtype="f64", roofline=res["roofline"],
+               matrix_check=res["matrix_check"])
+    if cpu_seconds > 0:
+        from hsd_amd import _lib as L
+        counts = eng.signature_counts()
+        n = g.n_node
+        rows = sample_nodes(n, 64, seed=3)
+        t0 = time.perf_counter()
+        ref = {}
+        for i in rows:
+            ref[int(i)] = corc.pair_rows_kl(counts, 0, spec["hop"], 0.5, False, int(i), int(i) + 1)[0]
+            if time.perf_counter() - t0 > cpu_seconds:
+                break
+        dt = time.perf_counter() - t0
+        eng.pair_prepare(L.METRIC_KL, 0, 0, spec["hop"], 0.5, False)
+        worst = 0.0
+        for i, want in ref.items():
+            got = eng.pair_rows_host(i, i + 1)[0]
+            # KL(i || j) for j > i, mirrored below the diagonal as model/HSD.py:132-134 does: compare the row's upper part
+            worst = max(worst, float(np.max(np.abs(got[i + 1:] - want[i + 1:]) / np.maximum(np.abs(want[i + 1:]), 1e-12))) if i + 1 < n else 0.0)
+        pairs = len(ref) * n
+        ent["cpu_baseline"] = dict(value=round(pairs / dt, 1), unit="node-pairs/s", cores=1, kind="port",
+                                   sample=f"{len(ref)} rows x {n} columns of the same matrix in {dt:.1f} s: C restatement (oracle/hsd_oracle.c) of "
+                                          f"tools/metrics.py:74-88 KL_divergence on the alpha = 0.5 smoothed histograms; host: {cpu_model()}")
+        ent["parity"] = dict(pairs_checked=int(sum(n - i - 1 for i in ref)), max_rel_err=worst, tol=1e-6, ok=bool(worst <= 1e-6))
+    return ent
+
+
+def run_config5(eng, cpu_seconds):
+    """MultiHSD.parallel_embed (model/multiscale_HSD.py:76-98): 8 log-spaced scales, Chebyshev order 50, threshold
+    1e-4/N, [sum, mean] per ring, K = 3 -> N x 64 fp64.  Unit: node signatures per second (N / wall).  The Chebyshev
+    recurrence is priced with SURVEY 8(d): bytes per order and impulse block of width C = 12 nnz(L) + 3 * 8 N C."""
+    import hsd_amd
+    from oracle import hsd_oracle as orc
+    spec = dict(graph="ba", nodes=50000, m=5)
+    g = make_graph(spec)
+    n, hop, S, order = g.n_node, 3, 8, 50
+    eng.sync()
+    t0 = time.perf_counter()
+    m = hsd_amd.MultiHSD(g, "ba50000", hop, S, engine=eng)
+    t_init = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    emb = m.parallel_embed(1, approx=True)
+    eng.sync()
+    t_first = time.perf_counter() - t0
+    # the device part alone, warm: one recurrence for all scales + ring sums
+    sets = [m._cheby(float(s), True) for s in m.scales]
+    coeffs = np.stack([c for c, _ in sets])
+    thr = 1e-4 / n
+    eng.sync()
+    t0 = time.perf_counter()
+    eng.multiscale_ring_stats(hop, coeffs, m.lmax, thr)
+    eng.sync()
+    t_dev = time.perf_counter() - t0
+    nnzL = g.n_edge * 2 + n
+    bytes_alg = order * (12.0 * nnzL * math.ceil(n / 512) + 24.0 * n * n)      # all impulse blocks (C = 512), all orders
+    ent = dict(config="configs[4]", workload="BASELINE configs[4]: model.multiscale_HSD heat-kernel signatures, 8 scales, "
+                                              "barabasi_albert N=50000 m=5 seed=42, K=3, Chebyshev order 50, threshold 1e-4/N",
+               nodes=n, edges=g.n_edge, hop=hop, scales=S, value=n / t_dev, unit="node signatures/s (8 scales x 4 rings x [sum, mean])",
+               seconds=round(t_dev, 4), dtype="f64",
+               roofline=dict(bound="hbm", achieved=round(bytes_alg / t_dev / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(bytes_alg / t_dev / 1e9 / HBM_PEAK_GBS, 4), traffic=load_traffic("ba_n50000_multihsd"),
+                             bytes_alg=bytes_alg, kernel="cheby_step / cheby_combine (K4): order x (12 nnz(L) per block + 24 N C)"),
+               phases_s=dict(lmax_estimate_and_setup=round(t_init, 4), parallel_embed_first_call=round(t_first, 4),
+                             device_recurrence_and_ring_sums_warm=round(t_dev, 4)))
+    if cpu_seconds > 0:
+        # CPU baseline: the PyGSP recurrence restated in numpy/scipy.sparse (oracle.cheby_heat_apply; PyGSP itself is
+        # absent, SURVEY 3.4) on a few unit impulses at once, all 8 scales, + get_triple; also the parity sample
+        from scipy.sparse import csr_matrix
+        rp, c, v = g.laplacian_csr()
+        Lm = csr_matrix((v, c, rp), shape=(n, n))
+        nodes = [int(x) for x in sample_nodes(n, 6, seed=5)]
+        E = np.zeros((n, len(nodes)))
+        for t, u in enumerate(nodes):
+            E[u, t] = 1.0
+        rings = {u: orc.khop_rings_node(g.rowptr, g.col, u, hop) for u in nodes}
+        t0 = time.perf_counter()
+        worst = 0.0
+        for si, s in enumerate(m.scales):
+            cc = orc.cheby_coeff_heat(s, m.lmax, order)
+            R = orc.cheby_heat_apply(Lm, cc, m.lmax, E)
+            for t, u in enumerate(nodes):
+                row = orc.threshold_wavelets(R[:, t], n)
+                ref = np.asarray(orc.get_triple(row[None, :], rings[u], 0))
+                got = np.asarray(emb[u][si * 2 * (hop + 1):(si + 1) * 2 * (hop + 1)])
+                # an entry within rounding of the 1e-4/N threshold may be kept by one side only (each flip moves a
+                # ring sum by at most 2e-9 at this N): absolute slack 2e-8
+                worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-2))))
+        dt = time.perf_counter() - t0
+        ent["cpu_baseline"] = dict(value=round(len(nodes) / dt, 3), unit="node signatures/s", cores=1, kind="port",
+                                   sample=f"{len(nodes)} source nodes x 8 scales in {dt:.1f} s: numpy/scipy.sparse restatement of pygsp cheby_op "
+                                          f"(model/HSD.py:55-59) + get_triple (model/multiscale_HSD.py:45-61); host: {cpu_model()}")
+        ent["parity"] = dict(nodes_checked=len(nodes), max_rel_err=worst, rel_err_floor=1e-2, tol=1e-6, ok=bool(worst <= 1e-6))
+    return ent
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -187,253 +616,114 @@ def main():
         # exchange is the library's own ncclAllGather over RCCL
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    rk = Ranks(dist, rank, world)
 
     import hsd_amd
-    from hsd_amd import _lib as L
 
-    P = world
-    n = int(round(args.nodes * math.sqrt(P)))
-    if args.graph == "er":
-        g = hsd_amd.erdos_renyi(n, args.mean_degree / n, seed=42)
-        gname = f"erdos_renyi N={n} p={args.mean_degree / n:g} seed=42"
-        if P > 1:
-            # the scaled-up G(n, 10/n) has ~n e^-10 isolated nodes; their empty rings make scipy (and
-            # Variant A) raise, so small components are tied to the giant one by one edge each
-            from hsd_amd.graph import connect_components
-            g = connect_components(g, seed=42)
-            gname += " + small components joined"
+    custom = any(v is not None for v in (args.graph, args.nodes, args.hop, args.metric)) or args.weak
+    if custom:
+        base = WORKLOADS["config2"] if (args.weak or args.graph in (None, "er")) else WORKLOADS["target"]
+        n = args.nodes if args.nodes is not None else (10000 if args.weak else base["nodes"])
+        if args.weak:
+            n = int(round(n * math.sqrt(world)))
+        kind = args.graph or base["graph"]
+        spec = dict(graph=kind, nodes=n, hop=args.hop if args.hop is not None else base["hop"], metric=args.metric or "wasserstein")
+        if kind == "er":
+            spec.update(p=args.mean_degree / n, connect=world > 1)
+            spec["name"] = f"erdos_renyi N={n} p={args.mean_degree / n:g} seed=42" + (" + small components joined" if world > 1 else "")
+        else:
+            spec.update(m=int(args.mean_degree / 2))
+            spec["name"] = f"barabasi_albert N={n} m={int(args.mean_degree / 2)} seed=42"
+        spec["name"] += f", K={spec['hop']}, {spec['metric']}" + (" (weak scaling: N = nodes * sqrt(P))" if args.weak else "")
+        tkey = f"{kind}_n{n}_K{spec['hop']}" if args.mean_degree == 10.0 else None
     else:
-        g = hsd_amd.barabasi_albert(n, int(args.mean_degree / 2), seed=42)
-        gname = f"barabasi_albert N={n} m={int(args.mean_degree / 2)} seed=42"
+        spec = dict(WORKLOADS[args.workload])
+        tkey = f"{spec['graph']}_n{spec['nodes']}_K{spec['hop']}"
+    g = make_graph(spec)
+    n = g.n_node
+    wass = spec["metric"] == "wasserstein"
+    primary_v = args.variant if wass else "KL"
+    variants = [primary_v] + ([("B" if args.variant == "A" else "A")] if wass and not args.no_secondary else [])
+
+    cfg_list = args.configs
+    if cfg_list is None:
+        cfg_list = "none" if custom or args.workload != "target" else ("2,3,5" if world == 1 else ("4" if world == 8 else "none"))
+    cfgs = [] if cfg_list == "none" else [c.strip() for c in cfg_list.split(",") if c.strip()]
 
     # ---- CPU baseline first (rank 0, single GPU only): the process pool forks, which must happen
     # before anything initialises the GPU in this process ----
-    cpu_runs = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.metric == "wasserstein":
-        single = scipy_baseline(g, args.hop, args.variant, args.cpu_seconds)
-        pool = scipy_pool_baseline(g, args.hop, args.variant, min(10.0, args.cpu_seconds), single[0])
-        cpu_runs = (single, pool)
+    cpu = None
+    cpu_pool = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and wass:
+        cpu = {primary_v: scipy_baseline(g, spec["hop"], primary_v, args.cpu_seconds)}
+        cpu_pool = scipy_pool_baseline(g, spec["hop"], primary_v, min(10.0, args.cpu_seconds), cpu[primary_v]["rate"])
 
     # HSD_COMM_DRYRUN=1 rehearses the multi-rank flow on a box with fewer GPUs than ranks: every rank on GPU 0,
     # no RCCL communicator, the signature exchange through the host (gloo) -- never a measurement
     dryrun = bool(os.environ.get("HSD_COMM_DRYRUN"))
     eng = hsd_amd.Engine(0 if dryrun else local_rank)
     info = eng.device_info()
-    eng.set_graph(g.rowptr, g.col)
-    from hsd_amd import distributed as hdist
-    r0, r1 = hdist.init_comm(eng, dist, rank, world) if world > 1 else (0, n)
-    assert (r0, r1) == hdist.shard_rows(n, world, rank)
+    r = run_degree_workload(eng, rk, g, spec, variants, args.steps, args.warmup, cpu=cpu, traffic_prefix=tkey, dryrun=dryrun)
+    prim = r["variants"][primary_v]
+    if "error" in prim:
+        raise ValueError(prim["error"])
 
-    # ---- K1 + K2: k-hop sweep and histogram signatures for this rank's sources ----
-    eng.sync()
-    t0 = time.perf_counter()
-    eng.signature_build_degree(args.hop, r0, r1)
-    eng.sync()
-    t_sig = time.perf_counter() - t0
-    # the sweep once more under the device stopwatch (buffers exist now), with its algorithmic bytes:
-    # sum over sources of sum_{v in ball_{K-1}} (8 + 4 deg v)  +  the histogram rows written
-    eng.timer_start()
-    eng.signature_build_degree(args.hop, r0, r1)
-    sweep_ms = eng.timer_stop()
-    sweep = None
-    if rank == 0:
-        sizes = eng.khop_sizes(args.hop, r0, min(r1, r0 + 2000))           # sample of sources for the ball sizes
-        deg_mean = float(g.degree.mean())
-        inner = float(sizes[:, :args.hop].sum(axis=1).mean())              # |ball_{K-1}| per source
-        bytes_sweep = (r1 - r0) * inner * (8.0 + 4.0 * deg_mean) + 4.0 * (r1 - r0) * (args.hop + 1) * eng.signature_dims()[1]
-        sweep = {"kernel": "khop_kernel (k-hop sweep + per-hop histograms)", "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
-                 "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1), "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "bound": "LDS atomics / latency (graph is L2-resident), not HBM"}
-    t0 = time.perf_counter()
-    hdist.allgather_signature(eng, dist, rank, world, via="host" if dryrun else "rccl")   # ONE ncclAllGather over xGMI
-    eng.sync()
-    t_gather = time.perf_counter() - t0
-
-    metric_code = {"wasserstein": L.METRIC_WASSERSTEIN, "kl": L.METRIC_KL, "symmetric_kl": L.METRIC_SYMMETRIC_KL}[args.metric]
-
-    def run_variant(variant):
-        align, lo, hi = variant_params(variant, args.hop)
-        t0 = time.perf_counter()
-        err = None
-        try:
-            eng.pair_prepare(metric_code, align, lo, hi, 0.5, False)
-            eng.sync()
-            t_prep = time.perf_counter() - t0
-            cols, ebytes = eng.pair_operand_dims()
-            mat = eng.pair_rows_device(r0, r1)
-            eng.sync()
-        except ValueError as e:             # Variant A raises on an empty ring, as scipy does
-            err = e
-        if dist is not None:
-            # an exception on SOME ranks must not leave the others waiting in the barriers of the timed loop
-            import torch
-            bad = torch.tensor([0 if err is None else 1], dtype=torch.int32)
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-            if int(bad[0]) and err is None:
-                err = ValueError("Distribution can't be empty. (raised on another rank)")
-        if err is not None:
-            raise err
-        wall, ev_ms = time_pair(eng, mat, r0, r1, args.steps, args.warmup, barrier)
-        return dict(variant=variant, wall=wall, ev_ms=ev_ms, cols=cols, ebytes=ebytes, mat=mat, t_prep=t_prep,
-                    align=align, lo=lo, hi=hi)
-
-    def finish(res):
-        wall = res["wall"]
-        if dist is not None:
-            import torch
-            t = torch.tensor([wall], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t[0])
-        pairs = n * (n - 1) / 2.0
-        value = pairs * args.steps / wall
-        # roofline of the all-pairs kernel, per launch (one launch per step at P = 1):
-        # algorithmic bytes = 8 * rows * N (each fp64 output written once) + operand matrix read once
-        rows = r1 - r0
-        bytes_alg = 8.0 * rows * n + float(res["ebytes"]) * n * res["cols"]
-        t_kernel = res["ev_ms"] * 1e-3 / args.steps
-        achieved = bytes_alg / t_kernel / 1e9
-        # arithmetic beside it: fp64 W1 needs 2 vector instructions per column pair,
-        # the uint32 path 1; ordered pairs actually evaluated by this rank
-        sq = rows * (rows + 1) / 2.0 + rows * (n - rows)
-        if res["ebytes"] == 4:
-            # uint32 kinds: one v_sad per column pair (zero-pad), or two v_mul_u32_u24 + one v_sad_u32
-            # (exact-integer form of the raw-sample W1)
-            instr, peak = sq * res["cols"] * (3.0 if res["align"] == 0 else 1.0), U32_VALU_PEAK
-        else:
-            instr, peak = sq * res["cols"] * (2.0 if args.metric == "wasserstein" else 1.0), FP64_VALU_PEAK
-        # HBM traffic per launch from the PMC passes of the same command (collected separately with
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; profiles/r01_traffic.json) -- None if this
-        # workload was not profiled
-        traffic = None
-        try:
-            with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f).get(f"{args.graph}_n{n}_K{args.hop}_{res['variant']}") if world == 1 and \
-                    args.metric == "wasserstein" and args.mean_degree == 10.0 else None
-        except OSError:
-            pass
-        out = dict(value=value, ms_per_step=wall * 1e3 / args.steps,
-                   roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                                 kernel_ms=round(t_kernel * 1e3, 4), bytes_alg=bytes_alg,
-                                 valu_frac=round(instr / t_kernel / peak, 4),
-                                 valu_peak_instr_per_s=peak, operand_columns=res["cols"]))
-        return out
-
-    primary = run_variant(args.variant)
-    prim = finish(primary)
-    n_bins = int(eng.signature_dims()[1])
-
-    def dtype_of(res):
-        """Arithmetic type of the kernel: fp64, uint32 SAD, or two uint16 columns per 32-bit word (v_sad_u16)."""
-        if res["ebytes"] != 4:
-            return "f64"
-        point = 1 if res["lo"] == 0 else 0
-        packed = (res["cols"] - point) < (res["hi"] - res["lo"] + 1 - point) * n_bins
-        return "u16" if packed else "u32"
-
-
-    # ---- parity sample + CPU baseline (rank 0, single GPU only) ----
-    cpu = None
-    cpu_pool = None
-    parity = None
-    if cpu_runs is not None:
-        (rate, npairs, nrows, sample, dt), (prate, pdone, workers, pdt) = cpu_runs
-        D = primary["mat"].rows_to_host(0, min(n, nrows + 1))
-        worst = 0.0
-        for (i, j), d in sample.items():
-            got = D[i, j]
-            worst = max(worst, abs(got - d) / max(abs(d), 1e-12))
-        parity = dict(pairs_checked=len(sample), max_rel_err=worst, tol=1e-6, ok=bool(worst <= 1e-6))
-        loop = ("model/HSD.py:140-161 (_calculate_worker): tools.metrics.calculate_distance = zero-pad + sort + "
-                "scipy.stats.wasserstein_distance per layer" if args.variant == "B" else
-                "model/HSD.py:103-112 calling scipy.stats.wasserstein_distance per layer")
-        cpu = dict(value=round(rate, 1), unit="node-pairs/s", cores=1, kind="port",
-                   sample=f"first {npairs} pairs (rows 0..{nrows}) of the same matrix, {dt:.1f} s; loop of {loop} on the "
-                          f"same degree signatures (variant {args.variant}); host: {cpu_model()}, {os.cpu_count()} cores")
-        cpu_pool = dict(value=round(prate, 1), unit="node-pairs/s", cores=workers, kind="port",
-                        sample=f"{pdone} pairs in {pdt:.1f} s over a multiprocessing.Pool({workers}), one task per source "
-                               f"row as model/HSD.py:118-130 submits them")
-    st = primary["mat"].stats()
-    primary["mat"].free()
-
-    secondary = None
-    if not args.no_secondary and args.metric == "wasserstein":
-        other = "B" if args.variant == "A" else "A"
-        try:
-            sec = run_variant(other)
-            fs = finish(sec)
-            sec["mat"].free()
-            secondary = dict(variant=other, value=fs["value"], ms_per_step=fs["ms_per_step"], roofline=fs["roofline"],
-                             dtype=dtype_of(sec))
-        except ValueError as e:           # Variant A raises on an empty ring, as scipy does
-            secondary = dict(variant=other, error=str(e))
-
-    # ---- the reference's own signature (heat coefficients, model/HSD.py:48-114) on the same graph: psi by the
-    # Chebyshev kernel, ragged sorted samples, all-pairs scipy-semantics W1.  Reported beside the headline, not
-    # part of it; dense psi, so only while N^2 doubles is small ----
-    heat = None
-    if rank == 0 and world == 1 and not args.no_secondary and args.metric == "wasserstein" and n <= 20000:
-        def timed(fn):
-            eng.sync()
-            t0 = time.perf_counter()
-            r = fn()
-            eng.sync()
-            return r, time.perf_counter() - t0
-        try:
-            hm = hsd_amd.HSD(g, "bench", 1.0, args.hop, "wasserstein", engine=eng)
-            hm._check_default_hierarchy()
-            psi, t_psi = timed(lambda: hm._wavelets_device(1.0, True))
-            _, t_samp = timed(lambda: eng.heat_signature_build(args.hop, psi))
-            DA, _ = timed(lambda: eng.pair_heat_rows_device(0, args.hop))
-            _, t_a = timed(lambda: eng.pair_heat_rows_device(0, args.hop, matrix=DA))
-            _, t_b = timed(lambda: eng.pair_heat_rowform_device(psi, matrix=DA))
-            DA.free()
-            psi.free()
-            pairs = n * (n - 1) / 2.0
-            nnzL = g.n_edge * 2 + n
-            cblk = min(n, 1024)
-            steps_total = 50 * math.ceil(n / cblk)
-            bytes_step = 12.0 * nnzL + 24.0 * n * cblk                      # SURVEY 8(d): per order and column block
-            t_step = t_psi / steps_total
-            heat_k4 = {"kernel": "cheby_step_kernel (one Chebyshev order of a 1024-impulse block)", "ms": round(t_step * 1e3, 4),
-                       "bytes_alg": bytes_step, "achieved_GBps": round(bytes_step / t_step / 1e9, 1),
-                       "frac_of_hbm": round(bytes_step / t_step / 1e9 / HBM_PEAK_GBS, 4),
-                       "bound": "gather of neighbour rows from the Infinity Cache / HBM (measured fetch 4x the algorithmic bytes)"}
-            heat = {"signature": "heat coefficients psi = exp(-L), Chebyshev order 50, threshold 1e-4/N",
-                    "wavelets_s": round(t_psi, 4), "sorted_ring_samples_s": round(t_samp, 4),
-                    "variant_A_pair_s": round(t_a, 4), "variant_A_pairs_per_s": pairs / t_a,
-                    "variant_B_as_written_pair_s": round(t_b, 4), "variant_B_as_written_pairs_per_s": pairs / t_b,
-                    "k4": heat_k4}
-        except (ValueError, MemoryError) as e:
-            heat = {"error": str(e)}
+    configs = []
+    if rank == 0 and world == 1:
+        csteps, cwarm = max(3, min(args.steps, 20)), 2
+        for c in cfgs:
+            try:
+                if c == "2":
+                    configs.append(run_config2(eng, rk, max(csteps, 50), 5, min(args.cpu_seconds, 16.0)))
+                elif c == "3":
+                    configs.append(run_config3(eng, rk, csteps, cwarm, min(args.cpu_seconds, 6.0)))
+                elif c == "5":
+                    configs.append(run_config5(eng, min(args.cpu_seconds, 10.0)))
+            except Exception as e:        # noqa: BLE001  (a side configuration must not lose the headline)
+                configs.append(dict(config=c, error=f"{type(e).__name__}: {e}"))
+    if world > 1 and "4" in cfgs:
+        # config 4 on the same ranks: a fresh context (new row partition and communicator for the larger graph)
+        eng.close()
+        eng = hsd_amd.Engine(0 if dryrun else local_rank)
+        spec4 = dict(WORKLOADS["config4"])
+        g4 = make_graph(spec4)
+        r4 = run_degree_workload(eng, rk, g4, spec4, ["B", "A"], max(3, min(args.steps, 10)), 2, dryrun=dryrun)
+        if rank == 0:
+            configs.append(dict(config="configs[3]", workload=spec4["name"], nodes=g4.n_node, edges=g4.n_edge, hop=3, bins=r4["n_bins"],
+                                n_gpus=world, rows_of_rank0=list(r4["rows"]), scaling="row blocks over all ranks",
+                                variants=[dict(variant_summary(r4["variants"][v]), kernel_ms_per_rank=r4["variants"][v].get("kernel_ms_per_rank"))
+                                          for v in ("B", "A")],
+                                other_kernels=[r4["sweep"]], phases_s=r4["phases"]))
 
     if rank == 0:
+        sec = None
+        if len(variants) > 1:
+            sec = variant_summary(r["variants"][variants[1]])
         line = {
             "metric": "node-pairs/sec on NxN structural-distance matrix",
-            "value": prim["value"], "unit": "node-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype_of(primary), "data": "synthetic" if not dryrun else "synthetic (HSD_COMM_DRYRUN rehearsal: all ranks on one GPU, not a measurement)",
-            "config": {"workload": f"{gname}, K={args.hop}, {args.metric}, degree-histogram signatures, "
-                                   f"variant {args.variant} ({'parallel_calculate_HSD, the call main.py:26 makes' if args.variant == 'B' else 'calculate_structural_distance'}; "
-                                   f"align={'zero-pad' if primary['align'] else 'none'}, "
-                                   f"layers {primary['lo']}..{primary['hi']}), full symmetric fp64 matrix resident in HBM",
-                       "nodes": n, "edges": g.n_edge, "hop": args.hop, "bins": n_bins,
-                       "parallelism": f"row-block x{world}"},
+            "value": prim["pairs_per_s"], "unit": "node-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
+            "dtype": prim["dtype"],
+            "data": "synthetic" if not dryrun else "synthetic (HSD_COMM_DRYRUN rehearsal: all ranks on one GPU, not a measurement)",
+            "config": {"workload": f"{spec['name']}, degree-histogram signatures, variant {primary_v} ({variant_call(primary_v) if wass else 'KL on alpha-smoothed ring histograms'}; "
+                                   f"layers {prim['lo']}..{prim['hi']}), full symmetric fp64 matrix resident in HBM",
+                       "nodes": n, "edges": g.n_edge, "hop": spec["hop"], "bins": r["n_bins"],
+                       "parallelism": f"row-block x{world}", "rows_of_rank0": list(r["rows"])},
             "roofline": prim["roofline"],
-            "cpu_baseline": cpu,
-            "cpu_baseline_pool": cpu_pool,
-            "parity": parity,
-            "secondary": secondary,
-            "heat_signature_path": heat,
-            "other_kernels": [k for k in (sweep,) if k],
-            "phases_s": {"khop_signature_build": round(t_sig, 4), "allgather": round(t_gather, 4),
-                         "operand_prepare": round(primary["t_prep"], 4),
-                         "end_to_end_one_matrix": round(t_sig + t_gather + primary["t_prep"] + prim["ms_per_step"] * 1e-3, 4)},
-            "matrix_check": {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")},
+            "cpu_baseline": cpu_entry(cpu[primary_v], primary_v, spec["hop"], "the same matrix") if cpu else None,
+            "cpu_baseline_pool": dict(value=round(cpu_pool["rate"], 1), unit="node-pairs/s", cores=cpu_pool["workers"], kind="port",
+                                      sample=f"{cpu_pool['pairs']} pairs in {cpu_pool['seconds']:.1f} s over a multiprocessing.Pool({cpu_pool['workers']}), "
+                                             f"one task per source row as model/HSD.py:118-130 submits them") if cpu_pool else None,
+            "parity": prim.get("parity"),
+            "secondary": sec,
+            "kernel_ms_per_rank": prim["kernel_ms_per_rank"],
+            "other_kernels": [k for k in (r["sweep"],) if k],
+            "phases_s": dict(r["phases"], operand_prepare_first=round(prim["t_prep"], 4),
+                             first_matrix_incl_allocation=round(prim["t_first"], 4),
+                             warm_prepare_plus_matrix=round(prim["t_warm"], 4),
+                             end_to_end_one_matrix_warm=round(r["phases"]["khop_signature_build"] + r["phases"]["allgather"] + prim["t_warm"], 4)),
+            "matrix_check": prim["matrix_check"],
+            "configs": configs,
             "device": info["arch"], "cus": info["compute_units"],
         }
         print(json.dumps(line), flush=True)

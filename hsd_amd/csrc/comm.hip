@@ -27,9 +27,17 @@ extern "C" int hsd_comm_unique_id(void *id128) {
     return HSD_OK;
 }
 
-static int set_shard(hsd_ctx *ctx, int world, int rank) {
+static int check_shard(hsd_ctx *ctx, int world, int rank) {
     if (world < 1 || rank < 0 || rank >= world) return hsd_fail(ctx, HSD_ERR_INVALID, "bad world/rank %d/%d", world, rank);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "upload the graph before hsd_comm_init");
+    return HSD_OK;
+}
+
+// Commits a row partition.  Only called once nothing can fail any more: a context never holds a
+// world > 1 partition without the communicator that goes with it.
+static void commit_shard(hsd_ctx *ctx, int world, int rank, ncclComm_t comm) {
+    hsd_comm_destroy_internal(ctx);
+    ctx->comm = reinterpret_cast<ncclComm *>(comm);
     ctx->world = world;
     ctx->rank = rank;
     // blocks of ceil(n / world) rows rounded up to whole 128-node tiles: every rank's block starts
@@ -40,27 +48,28 @@ static int set_shard(hsd_ctx *ctx, int world, int rank) {
     hsd_dev_free(ctx->d_counts);
     hsd_release_operands(ctx);
     ctx->hop = -1;
-    return HSD_OK;
 }
 
 extern "C" int hsd_comm_init(hsd_ctx *ctx, int world, int rank, const void *id128) {
     HSD_CHECK_CTX(ctx);
-    int rc = set_shard(ctx, world, rank);
+    int rc = check_shard(ctx, world, rank);
     if (rc) return rc;
-    hsd_comm_destroy_internal(ctx);
-    // a one-rank communicator is only created on request (HSD_FORCE_COMM=1): it lets a single-GPU
-    // box exercise the real ncclCommInitRank / in-place ncclAllGather path
-    if (world == 1 && !(id128 && getenv("HSD_FORCE_COMM"))) return HSD_OK;
-    // rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks: the row partition is set,
-    // no communicator is made (hsd_signature_allgather then fails; the caller exchanges through the host)
-    if (getenv("HSD_COMM_DRYRUN")) return HSD_OK;
-    if (!id128) return hsd_fail(ctx, HSD_ERR_INVALID, "null unique id");
-    ncclUniqueId id;
-    memcpy(&id, id128, sizeof id);
     ncclComm_t comm = nullptr;
-    ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
-    if (r != ncclSuccess) return hsd_fail(ctx, HSD_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
-    ctx->comm = reinterpret_cast<ncclComm *>(comm);
+    // a one-rank communicator is only created on request (HSD_FORCE_COMM=1): it lets a single-GPU
+    // box exercise the real ncclCommInitRank / in-place ncclAllGather path.
+    // HSD_COMM_DRYRUN: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks: the row
+    // partition is set, no communicator is made (hsd_signature_allgather then fails; the caller exchanges
+    // through the host)
+    const bool want_comm = !(world == 1 && !(id128 && getenv("HSD_FORCE_COMM"))) && !getenv("HSD_COMM_DRYRUN");
+    if (want_comm) {
+        if (!id128) return hsd_fail(ctx, HSD_ERR_INVALID, "null unique id");
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        // the communicator first; the old partition (and its communicator) stay in place if this fails
+        ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+        if (r != ncclSuccess) return hsd_fail(ctx, HSD_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    }
+    commit_shard(ctx, world, rank, comm);
     return HSD_OK;
 }
 

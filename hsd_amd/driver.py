@@ -18,22 +18,20 @@ from .model import HSD, MultiHSD
 
 
 def scale_boundary(e1, eN, eta=0.85, gamma=0.95):
-    """tools/util.py:120-125 (the GraphWave scale range)."""
-    t = np.sqrt(e1 * eN)
-    sMax = -np.log(eta) / t
-    sMin = -np.log(gamma) / t
-    return sMin, sMax
+    """The GraphWave scale interval the reference uses (tools/util.py:120-125): with g = sqrt(e1 * eN) the
+    geometric mean of the two eigenvalues, s_min = -ln(gamma) / g and s_max = -ln(eta) / g."""
+    geo_mean = np.sqrt(e1 * eN)
+    return -np.log(gamma) / geo_mean, -np.log(eta) / geo_mean
 
 
 def recommend_scale_range(eignvalues: list):
-    """tools/util.py:100-108: e1 = smallest eigenvalue above 0.001, eN = largest."""
-    eignvalues = sorted(eignvalues)
-    e1, en = eignvalues[0], eignvalues[-1]
-    for e in eignvalues:
-        if e > 0.001:
-            e1 = e
-            break
-    return scale_boundary(e1, en)
+    """(s_min, s_max) from a Laplacian spectrum (tools/util.py:100-108; the parameter keeps the reference's
+    spelling because callers pass it by name): e1 is the smallest eigenvalue above 0.001 -- the smallest
+    one of all if none is -- and eN the largest."""
+    spectrum = np.sort(np.asarray(eignvalues, dtype=float))
+    above = spectrum[spectrum > 0.001]
+    e1 = above[0] if above.size else spectrum[0]
+    return scale_boundary(e1, spectrum[-1])
 
 
 def laplacian_extreme_eigenvalues(g: Graph):

@@ -39,12 +39,28 @@ class DeviceMatrix:
 
     def __init__(self, engine, rows, cols, ld, row0):
         self.engine, self.rows, self.cols, self.ld, self.row0 = engine, rows, cols, ld, row0
+        self.ptr = None
         self.ptr = engine.malloc(rows * ld * 8)
 
     def free(self):
         if self.ptr:
-            self.engine.free(self.ptr)
-            self.ptr = None
+            ptr, self.ptr = self.ptr, None
+            self.engine.free(ptr)
+
+    # a matrix is up to 80 GB of HBM: it goes back when the object dies or leaves a `with` block, not only on free()
+    def __del__(self):
+        try:
+            if self.ptr and self.engine._ctx:
+                self.free()
+        except Exception:       # noqa: BLE001  (interpreter shutdown: the context may already be gone)
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+        return False
 
     def rows_to_host(self, a, b):
         """Rows [a, b) of the block (block-local indices) as a numpy array."""
@@ -75,7 +91,7 @@ class Engine:
         if st != L.OK:
             raise HsdError(f"hsd_create(device={device}) failed: {self.lib.hsd_strerror(st).decode()} "
                            "(is a ROCm GPU visible? hsd_amd has no CPU fallback)")
-        self._lock = threading.Lock()       # the ABI is not re-entrant per context
+        self._lock = threading.RLock()      # the ABI is not re-entrant per context (re-entrant lock: a DeviceMatrix finalizer may run inside _call)
         self.n = 0
         self.device = device
         self._owner = None
@@ -93,10 +109,23 @@ class Engine:
             pass
 
     def _call(self, name, *args):
+        # the message of a failed call is read under the same lock: another thread's call on this context
+        # would overwrite hsd_last_error in between
         with self._lock:
             st = getattr(self.lib, name)(self._ctx, *args)
-        if st != L.OK:
-            _raise(self.lib, self._ctx, st)
+            if st != L.OK:
+                _raise(self.lib, self._ctx, st)
+
+    def _call_into(self, matrix, owned, name, *args):
+        """_call for the helpers that fill a DeviceMatrix: one they allocated themselves is freed when the
+        library call raises (Variant A raises on empty rings AFTER the allocation: 80 GB at N = 100k)."""
+        try:
+            self._call(name, *args)
+        except BaseException:
+            if owned:
+                matrix.free()
+            raise
+        return matrix
 
     @staticmethod
     def _ptr(a):
@@ -245,11 +274,11 @@ class Engine:
     def pair_rows_device(self, r0=0, r1=None, matrix=None):
         """Asynchronous: D[r0:r1, :] into a resident DeviceMatrix (allocated if not given)."""
         r1 = self.n if r1 is None else r1
-        if matrix is None:
+        owned = matrix is None
+        if owned:
             ld = (self.n + 15) // 16 * 16       # rows start on 128-byte lines: every store of the pair kernel is a whole line
             matrix = DeviceMatrix(self, r1 - r0, self.n, ld, r0)
-        self._call("hsd_pair_rows", r0, r1, C.c_void_p(matrix.ptr), matrix.ld, 1)
-        return matrix
+        return self._call_into(matrix, owned, "hsd_pair_rows", r0, r1, C.c_void_p(matrix.ptr), matrix.ld, 1)
 
     # -- K4 / heat-coefficient signatures -----------------------------------
     def set_laplacian(self, rowptr, col, val):
@@ -273,9 +302,8 @@ class Engine:
         c1 = self.n if c1 is None else c1
         coeff = np.ascontiguousarray(coeff, dtype=np.float64)
         m = DeviceMatrix(self, c1 - c0, self.n, self.n, c0)
-        self._call("hsd_heat_wavelets", self._ptr(coeff), coeff.shape[0] - 1, C.c_double(lmax), C.c_double(threshold),
-                   c0, c1, C.c_void_p(m.ptr), m.ld, 1)
-        return m
+        return self._call_into(m, True, "hsd_heat_wavelets", self._ptr(coeff), coeff.shape[0] - 1, C.c_double(lmax),
+                               C.c_double(threshold), c0, c1, C.c_void_p(m.ptr), m.ld, 1)
 
     def heat_wavelets_multi_device(self, coeffs, lmax, threshold):
         """coeffs (n_scales, order+1) -> list of resident psi matrices, one Chebyshev recurrence for all."""
@@ -324,18 +352,19 @@ class Engine:
     def pair_heat_rows_device(self, layer_lo, layer_hi, r0=0, r1=None, matrix=None):
         """Variant A on the heat-coefficient samples into a resident DeviceMatrix."""
         r1 = self.n if r1 is None else r1
-        if matrix is None:
+        owned = matrix is None
+        if owned:
             matrix = DeviceMatrix(self, r1 - r0, self.n, self.n, r0)
-        self._call("hsd_pair_heat_rows", layer_lo, layer_hi, r0, r1, C.c_void_p(matrix.ptr), matrix.ld, 1)
-        return matrix
+        return self._call_into(matrix, owned, "hsd_pair_heat_rows", layer_lo, layer_hi, r0, r1, C.c_void_p(matrix.ptr), matrix.ld, 1)
 
     def pair_heat_rowform_device(self, psi, r0=0, r1=None, matrix=None):
         """Variant B as written (both samples from row startIndex of psi) into a resident DeviceMatrix."""
         r1 = self.n if r1 is None else r1
-        if matrix is None:
+        owned = matrix is None
+        if owned:
             matrix = DeviceMatrix(self, r1 - r0, self.n, self.n, r0)
-        self._call("hsd_pair_heat_rowform", C.c_void_p(psi.ptr), psi.ld, r0, r1, C.c_void_p(matrix.ptr), matrix.ld, 1)
-        return matrix
+        return self._call_into(matrix, owned, "hsd_pair_heat_rowform", C.c_void_p(psi.ptr), psi.ld, r0, r1,
+                               C.c_void_p(matrix.ptr), matrix.ld, 1)
 
     def pair_heat_rowform_host(self, psi, r0=0, r1=None):
         r1 = self.n if r1 is None else r1
@@ -355,8 +384,7 @@ class Engine:
         """numpy (rows, n) float64 -> DeviceMatrix (caller-assigned wavelets)."""
         a = np.ascontiguousarray(a, dtype=np.float64)
         m = DeviceMatrix(self, a.shape[0], a.shape[1], a.shape[1], 0)
-        self.memcpy_h2d(m.ptr, a, a.nbytes)
-        return m
+        return self._call_into(m, True, "hsd_memcpy_h2d", C.c_void_p(m.ptr), self._ptr(a), C.c_size_t(int(a.nbytes)))
 
     def matrix_stats(self, dev_ptr, rows, cols, ld, row0):
         out = np.empty(5, dtype=np.float64)

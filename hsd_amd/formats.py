@@ -36,25 +36,23 @@ def save_hierarchical_representation(graph, file_path: str, hop=7, engine=None):
 
 
 def read_hierarchy(file_path: str, maxHop: int) -> dict:
-    """tools/hierarchy.py:76-99, including its quirk: the trailing '#' leaves an empty token, so
-    the first missing ring reads as [''] (later ones as []); MultiHSD.get_triple skips ''."""
-    if not os.path.exists(file_path):
+    """Reader of the `.layers` format (behaviour of tools/hierarchy.py:76-99).  Every record is cut at
+    '#' and the first maxHop + 1 fields become rings (split at ','); fields a record does not have are
+    empty rings.  The writer's trailing '#' therefore leaves one empty FIELD behind the last ring, which
+    comes back as [''] -- a quirk readers of the reference's files depend on (MultiHSD.get_triple skips
+    the '' token), so it is reproduced.  Reading stops at the first blank line."""
+    if not os.path.isfile(file_path):
         raise FileNotFoundError(f"path:{file_path}, hierarchy file not exist")
+    n_rings = maxHop + 1
     hierarchy = {}
-    with open(file_path, mode="r", encoding="utf-8") as fin:
-        while True:
-            line = fin.readline().strip()
-            if not line:
+    with open(file_path, encoding="utf-8") as fin:
+        for raw in fin:
+            record = raw.strip()
+            if record == "":
                 break
-            layers = []
-            neighbor_layer = line.split("#")
-            for hop in range(0, maxHop + 1):
-                if hop >= len(neighbor_layer):
-                    layer = []
-                else:
-                    layer = neighbor_layer[hop].strip().split(",")
-                layers.append(layer)
-            hierarchy[layers[0][0]] = layers
+            fields = record.split("#")[:n_rings]
+            rings = [f.strip().split(",") for f in fields] + [[] for _ in range(n_rings - len(fields))]
+            hierarchy[rings[0][0]] = rings
     print(f"done, number of nodes: {len(hierarchy)}")
     return hierarchy
 
@@ -110,16 +108,18 @@ def read_distance(path: str, n_nodes: int) -> np.ndarray:
 
 # ---- labels -----------------------------------------------------------------------------------
 def read_label(path) -> dict:
-    """tools/dataloader.py:57-75: `node label` per line; a missing file yields {} with a message."""
-    label_dict = dict()
-    try:
-        with open(path, mode="r", encoding="utf-8") as fin:
-            while True:
-                line = fin.readline().strip()
-                if not line:
-                    break
-                node, label = line.split(" ")
-                label_dict[node] = int(label)
-    except FileNotFoundError:
+    """`node label` per line, separated by one blank (behaviour of tools/dataloader.py:57-75): labels are
+    ints, node ids stay strings, reading stops at the first blank line, and a missing file is reported on
+    stdout and yields {} instead of raising."""
+    labels = {}
+    if not os.path.isfile(path):
         print(f"Lable file not exist, path:{path}")
-    return label_dict
+        return labels
+    with open(path, encoding="utf-8") as fin:
+        for raw in fin:
+            record = raw.strip()
+            if record == "":
+                break
+            node, label = record.split(" ")
+            labels[node] = int(label)
+    return labels

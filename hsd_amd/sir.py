@@ -53,19 +53,18 @@ class SIR:
 
 
 def split_nodes(graph, n_class, infect_prob, t=5, save_path=None, engine=None) -> dict:
-    """tools/SIR.py:83-93."""
-    model = SIR(graph, p=infect_prob, t=t, engine=engine)
-    model.start()
-    labels = model.label_nodes(n_class)
+    """Influence classes of every node, optionally written as a label file ordered by integer node id
+    (what tools/SIR.py:83-93 produces)."""
+    labels = get_SIR_labels(graph, n_class, t, infect_prob, engine=engine)
     if save_path:
-        with open(save_path, mode="w+", encoding="utf-8") as fout:
-            for node, label in sorted(labels.items(), key=lambda x: int(x[0])):
-                fout.write("{} {}\n".format(node, label))
+        lines = [f"{node} {labels[node]}\n" for node in sorted(labels, key=int)]
+        with open(save_path, "w", encoding="utf-8") as fout:
+            fout.writelines(lines)
     return labels
 
 
 def get_SIR_labels(g, n: int, t: int, infect_p: float, engine=None) -> dict:
-    """tools/SIR.py:95-100."""
-    sir = SIR(g, infect_p, t, engine=engine)
-    sir.start()
-    return sir.label_nodes(n_class=n)
+    """Shortcut of tools/SIR.py:95-100: t rounds from every origin, then n influence classes."""
+    model = SIR(g, p=infect_p, t=t, engine=engine)
+    model.start()
+    return model.label_nodes(n)
