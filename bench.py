@@ -205,19 +205,28 @@ def _pool_row(task):
 
 def scipy_pool_baseline(g, hop, variant, budget_s, single_rate):
     """The same loop fanned out over a process pool of os.cpu_count() workers, one task per source row
-    (model/HSD.py:118-130), sized from the single-core rate to last about budget_s."""
+    (model/HSD.py:118-130).  Tasks are short (about a quarter second of one core each) and the pool is stopped at the
+    budget: the rate is pairs finished / elapsed, whatever the per-core rate under full load turns out to be."""
     import multiprocessing as mp
     workers = min(os.cpu_count() or 1, 64)
-    per_task = max(16, int(single_rate * budget_s / 4))            # ~4 tasks per worker
-    n_tasks = workers * 4
-    nodes = sample_nodes(g.n_node, min(g.n_node, n_tasks + per_task + 1), seed=11)
-    tasks = [(i, per_task) for i in range(min(n_tasks, len(nodes) - 1))]
+    per_task = max(8, int(single_rate * 0.25))
+    n_tasks = workers * 256
+    nodes = sample_nodes(g.n_node, min(g.n_node, max(640, per_task + 64)), seed=11)
+    tasks = [(i % (len(nodes) - per_task - 1), per_task) for i in range(n_tasks)]
     ctx = mp.get_context("fork")
-    with ctx.Pool(workers, initializer=_pool_init,
-                  initargs=(g.rowptr, g.col, hop, g.degree.astype(np.float64), nodes, variant)) as pool:
+    pool = ctx.Pool(workers, initializer=_pool_init, initargs=(g.rowptr, g.col, hop, g.degree.astype(np.float64), nodes, variant))
+    done = 0
+    try:
+        pool.map(_pool_row, [(0, 0)] * (4 * workers), chunksize=1)      # every worker has built its ring samples before the clock starts
         t0 = time.perf_counter()
-        done = sum(pool.map(_pool_row, tasks, chunksize=1))
+        for k in pool.imap_unordered(_pool_row, tasks, chunksize=1):
+            done += k
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
+    finally:
+        pool.terminate()
+        pool.join()
     return dict(rate=done / dt, pairs=done, workers=workers, seconds=dt)
 
 
@@ -277,17 +286,20 @@ def kernel_roofline(n, rows, res, steps, metric, traffic_key=None):
     bytes_alg = 8.0 * rows * n + float(res["ebytes"]) * n * res["cols"]
     t_kernel = res["ev_ms"] * 1e-3 / steps
     achieved = bytes_alg / t_kernel / 1e9
-    sq = rows * (rows + 1) / 2.0 + rows * (n - rows)            # pairs this rank evaluates (diagonal square once)
+    # vector instructions of one launch: (operand words x pairs) the kernel itself counted (hsd_pair_work; whole tiles, and
+    # fewer words than `cols` where a tile pair took the shorter rank form of a zero-pad layer) x instructions per word pair
+    sq = rows * (rows + 1) / 2.0 + rows * (n - rows)            # pairs this rank owes (diagonal square once)
+    work = res.get("work") or sq * res["cols"]
     if res["ebytes"] == 4:
-        instr, peak = sq * res["cols"] * (3.0 if res["align"] == 0 else 1.0), SAD_VALU_PEAK
+        instr, peak = work * 1.0, SAD_VALU_PEAK                  # one v_sad_u32 / v_sad_u16 per word pair
     else:
-        instr, peak = sq * res["cols"] * (2.0 if metric == "wasserstein" else 1.0), FP64_VALU_PEAK
+        instr, peak = work * (2.0 if metric == "wasserstein" else 1.0), FP64_VALU_PEAK   # sub + add|.| per column pair; KL: one FMA
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                 traffic=load_traffic(traffic_key) if traffic_key else None,
                 kernel_ms=round(t_kernel * 1e3, 4), bytes_alg=bytes_alg,
                 valu_frac=round(instr / t_kernel / peak, 4), valu_peak_lane_instr_per_s=peak,
                 limiter="vector ALU issue" if instr / peak > bytes_alg / (HBM_PEAK_GBS * 1e9) else "HBM write stream",
-                operand_columns=res["cols"])
+                operand_columns=res["cols"], columns_evaluated_per_pair=round(work / sq, 2))
 
 
 def dtype_of(res, n_bins):
@@ -398,7 +410,8 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
             out[variant] = dict(variant=variant, error=str(err) if err else "Distribution can't be empty. (raised on another rank)")
             continue
         wall, ev_ms = time_pair(eng, mat, r0, r1, steps, warmup, rk.barrier)
-        res = dict(variant=variant, wall=rk.max(wall), wall_rank=wall, ev_ms=ev_ms, cols=cols, ebytes=ebytes, align=align, lo=lo, hi=hi,
+        work = eng.pair_work()                          # of the last launch
+        res = dict(work=work, variant=variant, wall=rk.max(wall), wall_rank=wall, ev_ms=ev_ms, cols=cols, ebytes=ebytes, align=align, lo=lo, hi=hi,
                    t_prep=t_prep, t_first=t_first, t_warm=t_warm, rows=(r0, r1))
         key = f"{traffic_prefix}_{variant}" if traffic_prefix and rk.world == 1 else None
         res["roofline"] = kernel_roofline(n, r1 - r0, res, steps, metric, key)
@@ -576,7 +589,7 @@ def run_config5(eng, cpu_seconds):
         from scipy.sparse import csr_matrix
         rp, c, v = g.laplacian_csr()
         Lm = csr_matrix((v, c, rp), shape=(n, n))
-        nodes = [int(x) for x in sample_nodes(n, 6, seed=5)]
+        nodes = [int(x) for x in sample_nodes(n, 32, seed=5)]
         E = np.zeros((n, len(nodes)))
         for t, u in enumerate(nodes):
             E[u, t] = 1.0

@@ -72,6 +72,7 @@ SIGNATURES = {
     "hsd_pair_rows": (_int, [_p, _i64, _i64, _p, _i64, _int]),
     "hsd_pair_topk": (_int, [_p, _int, _i64, _i64, _p, _p]),
     "hsd_pair_operand_dims": (_int, [_p, C.POINTER(_int), C.POINTER(_int)]),
+    "hsd_pair_work": (_int, [_p, C.POINTER(C.c_double)]),
     "hsd_set_laplacian": (_int, [_p, _i64, _p, _p, _p]),
     "hsd_heat_wavelets": (_int, [_p, _p, _int, C.c_double, C.c_double, _i64, _i64, _p, _i64, _int]),
     "hsd_heat_wavelets_multi": (_int, [_p, _p, _int, _int, C.c_double, C.c_double, _p, _i64]),

@@ -24,13 +24,15 @@ enum PairMode {
     PAIR_KL = 4,          // H[i] - sum_c P[c][i] * LP[c][j]               (mirrored upper triangle)
     PAIR_SKL = 5,         // (H[i] + H[j] - P_i.LP_j - P_j.LP_i) / 2
     PAIR_SAD_U16 = 6,     // as PAIR_SAD_U32 with two uint16 columns per word (v_sad_u16)
-    PAIR_RAT_U32 = 7,     // W1 raw samples in exact integers: sum_c |cc_i n_j - cc_j n_i| / (n_i n_j)
 };
 
 constexpr int HSD_TILE = 128;      // pair tile edge (nodes)
 constexpr int HSD_CHUNK = 16;      // columns staged per LDS pass
 constexpr int HSD_MAX_LAYERS = 32;
 constexpr int HSD_LCHUNK = 64;     // CSR entries per chunk of a long Laplacian row
+
+// One layer of a zero-pad distance: where its bin-form and (optional) rank-form operand columns live (csrc/pair.hip)
+struct HsdSegDesc { int bin_col0, bin_words, rank_col0, rank_cap; };
 
 struct hsd_ctx {
     int device = 0;
@@ -70,7 +72,12 @@ struct hsd_ctx {
     void *d_X = nullptr;               // fp64 or u32 [dcols][npad]
     void *d_Y = nullptr;               // KL: log P, same shape
     double *d_H = nullptr;             // KL: sum_c P log P per node [npad]
-    uint32_t *d_nring = nullptr;       // PAIR_RAT_U32: ring sizes per layer [n_seg][npad]
+    HsdSegDesc seg_tab[HSD_MAX_LAYERS] = {};   // zero-pad: per layer segment, bin-form / rank-form columns
+    HsdSegDesc *d_seg_tab = nullptr;
+    uint32_t *d_rmax = nullptr;        // zero-pad rank form: largest ring per layer and 64-node granule [n_seg][ngran]
+    int ngran = 0;
+    int list_cap = 0;                  // entries of the pair kernel's per-tile chunk list (LDS)
+    unsigned long long *d_work = nullptr;   // operand words x pairs evaluated by the last hsd_pair_rows (hsd_pair_work)
     double *d_inv = nullptr;           // zero-pad: 1/ring size per layer [n_seg][npad]
     int n_seg = 0;                     // zero-pad: number of layer segments
     int seg_valid16 = 0;               // PAIR_SAD_U16: packed data columns per segment

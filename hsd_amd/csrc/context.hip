@@ -50,7 +50,9 @@ extern "C" int hsd_create(int device, hsd_ctx **out) {
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->d_flag), 4 * sizeof(int)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_flag), 4 * sizeof(int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_work), sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_work, 0, sizeof(unsigned long long)) != hipSuccess) {
         hsd_destroy(ctx);          // releases whatever was created (all members start null)
         return HSD_ERR_HIP;
     }
@@ -64,7 +66,8 @@ void hsd_release_operands(hsd_ctx *ctx) {
     ctx->d_X = ctx->d_Y = nullptr;
     hsd_dev_free(ctx->d_H);
     hsd_dev_free(ctx->d_inv);
-    hsd_dev_free(ctx->d_nring);
+    hsd_dev_free(ctx->d_seg_tab);
+    hsd_dev_free(ctx->d_rmax);
     ctx->mode = PAIR_NONE;
 }
 
@@ -84,6 +87,7 @@ extern "C" void hsd_destroy(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_node_bin);
     hsd_dev_free(ctx->d_support);
     hsd_dev_free(ctx->d_flag);
+    hsd_dev_free(ctx->d_work);
     hsd_dev_free(ctx->d_stage);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (auto &t : ctx->tile_lists) (void)hipFree(t.d);

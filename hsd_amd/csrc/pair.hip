@@ -39,15 +39,15 @@ namespace {
 
 // operand columns per LDS stage: 16 fp64 or 32 uint32 columns (the same LDS bytes); segments of
 // the operand matrices are padded to this width by hsd_pair_prepare
-__host__ __device__ constexpr int chunk_cols(int kind) { return (kind == 1 || kind == 4 || kind == 5) /* uint32 kinds */ ? 32 : 16; }
+__host__ __device__ constexpr int chunk_cols(int kind) { return (kind == 1 || kind == 4) /* uint32 kinds */ ? 32 : 16; }
 constexpr int NT = 256;             // 4 waves; wave w owns quadrant (w>>1, w&1) of the tile
 
+struct SegDesc;
 struct PairArgs {
     const void *X;          // I-side operand, bin-major [dcols][npad]
     const void *Y;          // J-side operand (same as X for the L1 kernels)
     const double *H;        // DOT: per-node entropy term
     const double *inv;      // segmented: [n_seg][npad]
-    const uint32_t *nring;  // K_RAT: ring sizes [n_seg][npad]
     const double *point;    // optional ring-0 value per node [npad] (adds |p_i - p_j|)
     double *out;
     int64_t ld, npad;
@@ -61,8 +61,11 @@ struct PairArgs {
     int hmode;              // DOT: 0 -> H[i] - acc ; 1 -> (H[i] + H[j] - acc) / 2
     int dcols, n_seg;
     int dcols_valid;        // columns that carry data (non-segmented kinds)
-    int seg_stride;         // padded columns per segment (all layers are equally wide)
-    int seg_valid;          // data columns per segment
+    const struct SegDesc *seg_tab;   // segmented kinds: per layer, where its bin-form / rank-form columns live
+    const uint32_t *rmax;   // [n_seg][ngran] largest ring of the layer within each 64-node granule (rank form)
+    int ngran;
+    int list_cap;           // entries of the per-tile chunk list in LDS
+    unsigned long long *work;   // += operand words x pairs evaluated (hsd_pair_work), or nullptr
     int dbg;                // HSD_DEBUG ablation bits: 1 = no stores, 2 = no arithmetic
     // fused k-nearest consumer (hsd_pair_topk): instead of storing the tile, every value below its
     // row's threshold tau is appended to that row's candidate list
@@ -73,12 +76,11 @@ struct PairArgs {
     int cand_cap;
 };
 
-enum { K_L1 = 0, K_SAD = 1, K_ZP = 2, K_DOT = 3, K_SAD16 = 4, K_RAT = 5 };
+enum { K_L1 = 0, K_SAD = 1, K_ZP = 2, K_DOT = 3, K_SAD16 = 4 };
 
 template <int KIND> struct Elem { using type = double; };
 template <> struct Elem<K_SAD> { using type = uint32_t; };
 template <> struct Elem<K_SAD16> { using type = uint32_t; };      // two uint16 columns per word
-template <> struct Elem<K_RAT> { using type = uint32_t; };        // cumulative counts x bin width
 template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<uint32_t> { using type = uint2; };
@@ -92,18 +94,21 @@ typedef __attribute__((address_space(1))) v2f64 gdouble2;
 typedef __attribute__((address_space(1))) const double gcdouble;
 typedef __attribute__((address_space(1))) const uint32_t gcu32;
 
-__device__ inline void decode_tile(const PairArgs &a, int b, int &ti, int &tj) {
-    // XCD-aware order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each
-    // XCD a contiguous run of tiles -- consecutive tiles share their I block in that XCD's L2.
-    const int nb = a.ntiles;
-    const int q = nb >> 3, r = nb & 7, x = b & 7, idx = b >> 3;
-    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+__device__ inline int64_t uniform64(int64_t v) {
+    // a wave-uniform value that the compiler may have left in vector registers: back to scalar registers
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// position t of the tile order -> tile coordinates
+__device__ inline void tile_from_index(const PairArgs &a, int t, int &ti, int &tj) {
     if (a.tiles) {
         // super-tile-major order built by the host: the 2S operand blocks of an S x S group of
         // tiles are fetched from HBM once and then served by the XCD's L2
+        // (the coordinates are wave-uniform: keep them in scalar registers, and everything derived from them with them)
         const int2 tt = a.tiles[__builtin_amdgcn_readfirstlane(t)];
-        ti = tt.x;
-        tj = tt.y;
+        ti = __builtin_amdgcn_readfirstlane(tt.x);
+        tj = __builtin_amdgcn_readfirstlane(tt.y);
         return;
     }
     if (a.sym) {
@@ -113,18 +118,33 @@ __device__ inline void decode_tile(const PairArgs &a, int b, int &ti, int &tj) {
         row = max(0, min(T - 1, row));
         while (row > 0 && (int64_t)row * T - (int64_t)row * (row - 1) / 2 > t) --row;
         while ((int64_t)(row + 1) * T - (int64_t)(row + 1) * row / 2 <= t) ++row;
-        ti = row;
-        tj = row + (t - (int)((int64_t)row * T - (int64_t)row * (row - 1) / 2));
+        ti = __builtin_amdgcn_readfirstlane(row);
+        tj = __builtin_amdgcn_readfirstlane(row + (t - (int)((int64_t)row * T - (int64_t)row * (row - 1) / 2)));
     } else {
         ti = t / a.tiles_j;
         tj = t % a.tiles_j;
     }
 }
 
+__device__ inline void decode_tile(const PairArgs &a, int b, int &ti, int &tj) {
+    // XCD-aware order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each
+    // XCD a contiguous run of tiles -- consecutive tiles share their I block in that XCD's L2.
+    const int nb = a.ntiles;
+    const int q = nb >> 3, r = nb & 7, x = b & 7, idx = b >> 3;
+    tile_from_index(a, (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx, ti, tj);
+}
+
 __device__ inline void glds16(const void *g, void *lds_wave_base) {
     // asynchronous global -> LDS copy, 16 B per lane, LDS address = wave-uniform base + 16 * lane
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// The same with the instruction form spelled out: scalar 64-bit base + one 32-bit per-lane offset, LDS address in M0.
+// (Inside the persistent kernel hipcc re-associates base + offset and keeps one 64-bit VECTOR address per instruction
+// live across the tile loop -- 16 register pairs, spilled to scratch and reloaded behind s_waitcnt vmcnt(0).)
+__device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory", "m0");
 }
 
 // Stage CH columns x BT nodes of one operand: LDS image [CH][BT] of T (linear, as in memory).
@@ -179,28 +199,17 @@ __device__ inline void store2_full(gdouble *p, double v0, double v1, bool nt) {
     }
 }
 
-// s_waitcnt vmcnt(n) needs an immediate.  n = result stores issued after the newest operand
-// request; vmcnt retires in order, so "all but the n youngest" means the operands have landed.
-__device__ inline void wait_vm_except(int n) {
-    switch (n >> 2) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;     // waits for more than needed: safe
-    }
-}
+// One layer ("segment") of a zero-pad distance has two exact representations of the same integer
+//   S(i, j) = |n_i - n_j| s_0 + sum_b |T_i(b) - T_j(b)| (s_{b+1} - s_b)  =  sum_r |u_i(r) - u_j(r)|
+// (area between the two tail-count step functions = L1 distance of the descending sorted samples, zero padded):
+//   bin form   one column per support bin (tail count x bin width)          -> bin_words words, every tile pair
+//   rank form  one column per rank r (r-th largest member value, 0 beyond)  -> ceil(R / 2) words, R = largest ring
+//              of the layer among the nodes of the two tiles
+// A tile pair evaluates whichever is shorter: sparse layers (ring 1 of a scale-free graph: 10 members against 241
+// degree bins) cost a few words instead of 120.  Same integer, so the result is bit-identical either way.
+struct SegDesc : HsdSegDesc {};    // columns in words; rank_col0 < 0: no rank form
 
-// A workgroup walks tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...  With gridDim.x == ntiles it
-// computes exactly one tile.  With a resident-sized grid (persistent launch) the operand request
-// for the NEXT tile is issued before the result stores of the current one, and the next tile's
-// first wait lets those stores stay in flight: the matrix drains to HBM under the next tile's
-// arithmetic instead of between two workgroups' lifetimes.
+// A workgroup computes exactly one tile.
 template <int KIND, bool FAST, int TR>
 __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArgs a) {
     using T = typename Elem<KIND>::type;
@@ -208,10 +217,13 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
     constexpr int TC = TR;
     constexpr int WQ = 8 * TR;                       // quadrant edge owned by one wave
     constexpr int BT = 2 * WQ;                       // tile edge: 64 (TR = 4) or 128 (TR = 8)
-    constexpr bool SEG = (KIND == K_SAD || KIND == K_ZP || KIND == K_SAD16 || KIND == K_RAT);
+    constexpr bool SEG = (KIND == K_SAD || KIND == K_ZP || KIND == K_SAD16);
     constexpr int CH = chunk_cols(KIND);             // operand columns per LDS stage
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     T *sbase = reinterpret_cast<T *>(lds_raw);       // stage s: I at s*2*CH*BT, J right behind it
+    // SEG kinds: the tile's chunk list {first column, valid | ends_segment << 8 | segment << 16} behind the stages
+    int2 *clist = reinterpret_cast<int2 *>(sbase + 4 * CH * BT);
+    int *nlist_p = reinterpret_cast<int *>(clist + a.list_cap);
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int ly = l >> 3, lx = l & 7;
@@ -228,30 +240,515 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
     gcdouble *const gH = (gcdouble *)a.H;
     gcdouble *const ginv = (gcdouble *)a.inv;
     gcdouble *const gpoint = (gcdouble *)a.point;
-    const int nchunks = a.dcols / CH;
     const bool nt = !(a.dbg & 4);                    // HSD_DEBUG bit 2: plain instead of non-temporal stores
 
-    auto request = [&](int64_t ri0, int64_t rj0) __attribute__((always_inline)) {
-        // the first two operand chunks of a tile: both LDS stages are free at this point
-        if (nchunks > 0) {
-            stage_side<T, FAST, BT, CH>(XI, a.npad, 0, ri0, sbase, tid);
-            stage_side<T, FAST, BT, CH>(XJ, a.npad, 0, rj0, sbase + CH * BT, tid);
-            if constexpr (FAST) {
-                if (nchunks > 1) {
-                    stage_side<T, true, BT, CH>(XI, a.npad, CH, ri0, sbase + 2 * CH * BT, tid);
-                    stage_side<T, true, BT, CH>(XJ, a.npad, CH, rj0, sbase + 3 * CH * BT, tid);
-                }
-            }
-        }
-    };
-
-    int t = blockIdx.x;
+    const int t = blockIdx.x;
     if (t >= a.ntiles) return;
     int ti, tj;
     decode_tile(a, t, ti, tj);
-    int64_t i0 = a.i_begin + (int64_t)ti * BT, j0 = a.j_begin + (int64_t)tj * BT;
-    request(i0, j0);
-    int stores_behind = 0;          // result stores issued after the newest operand request
+    const int64_t i0 = a.i_begin + (int64_t)ti * BT, j0 = a.j_begin + (int64_t)tj * BT;
+
+    int nchunks = a.dcols / CH;
+    if constexpr (SEG) {
+        if (w == 0) {
+            // lane s decides segment s: bin form, or rank form if the largest ring of the layer among the nodes of
+            // both tiles needs fewer words (rmax: per 64-node granule maxima of the ring sizes)
+            int col0 = 0, words = 0;
+            if (l < a.n_seg) {
+                const SegDesc sd = a.seg_tab[l];
+                col0 = sd.bin_col0;
+                words = sd.bin_words;
+                if (sd.rank_col0 >= 0) {
+                    const uint32_t *rm = a.rmax + (int64_t)l * a.ngran;
+                    uint32_t R = 0;
+                    for (int64_t g = i0 >> 6; g <= (i0 + BT - 1) >> 6; ++g) R = max(R, rm[g]);
+                    for (int64_t g = j0 >> 6; g <= (j0 + BT - 1) >> 6; ++g) R = max(R, rm[g]);
+                    const int wr = (KIND == K_SAD16) ? (int)((R + 1) >> 1) : (int)R;
+                    if (wr <= sd.rank_cap) { col0 = sd.rank_col0; words = wr; }
+                }
+            }
+            const int nch = (words + CH - 1) / CH;
+            int pre = nch;                            // inclusive prefix over the lanes = end of this segment's chunks
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(pre, o, 64);
+                if (l >= o) pre += up;
+            }
+            for (int c = 0; c < nch; ++c)
+                clist[pre - nch + c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+            if (l == 63) *nlist_p = pre;
+        }
+        __syncthreads();
+        nchunks = __builtin_amdgcn_readfirstlane(*nlist_p);
+    }
+    auto chunk_col = [&](int k) __attribute__((always_inline)) -> int {
+        if constexpr (SEG) return __builtin_amdgcn_readfirstlane(clist[k].x);
+        else return k * CH;
+    };
+
+    // the first two operand chunks: both LDS stages are free at this point
+    if (nchunks > 0) {
+        const int c0 = chunk_col(0);
+        stage_side<T, FAST, BT, CH>(XI, a.npad, c0, i0, sbase, tid);
+        stage_side<T, FAST, BT, CH>(XJ, a.npad, c0, j0, sbase + CH * BT, tid);
+        if constexpr (FAST) {
+            if (nchunks > 1) {
+                const int c1 = chunk_col(1);
+                stage_side<T, true, BT, CH>(XI, a.npad, c1, i0, sbase + 2 * CH * BT, tid);
+                stage_side<T, true, BT, CH>(XJ, a.npad, c1, j0, sbase + 3 * CH * BT, tid);
+            }
+        }
+    }
+
+    double acc[TR][TC];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[r][c] = 0.0;
+    T part[TR][TC];
+    if constexpr (SEG) {
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) part[r][c] = (T)0;
+    }
+    unsigned long long work = 0;                     // operand words x pairs this tile evaluates (hsd_pair_work)
+    for (int k = 0; k < nchunks; ++k) {
+        // columns of this chunk that carry data (the tail of a segment is zero padding)
+        int cvalid, seg = 0;
+        bool ends_seg = false;
+        if constexpr (SEG) {
+            const int meta = __builtin_amdgcn_readfirstlane(clist[k].y);
+            cvalid = meta & 0xff;
+            ends_seg = (meta & 0x100) != 0;
+            seg = meta >> 16;
+        } else {
+            cvalid = min(CH, a.dcols_valid - k * CH);
+        }
+        work += (unsigned)cvalid;
+        if (a.dbg & 2) cvalid = 0;
+        if constexpr (FAST) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
+        const T *sI = sbase + (size_t)(FAST ? (k & 1) : 0) * 2 * CH * BT;
+        const T *sJ = sI + CH * BT;
+        if constexpr (FAST) {
+            if (k > 0 && k + 1 < nchunks) {
+                T *nI = sbase + (size_t)((k + 1) & 1) * 2 * CH * BT;
+                const int cn = chunk_col(k + 1);
+                stage_side<T, true, BT, CH>(XI, a.npad, cn, i0, nI, tid);
+                stage_side<T, true, BT, CH>(XJ, a.npad, cn, j0, nI + CH * BT, tid);
+            }
+        }
+        // operands are double-buffered in registers: the LDS reads of column c+1 are in flight
+        // while column c is being accumulated
+        T av[2][TR], bv[2][TC];
+        auto load_ops = [&](int c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < TR / 2; ++q) {
+                const T2 v = *reinterpret_cast<const T2 *>(sI + c * BT + wi + 16 * q);
+                av[buf][2 * q] = v.x;
+                av[buf][2 * q + 1] = v.y;
+            }
+#pragma unroll
+            for (int q = 0; q < TC / 2; ++q) {
+                const T2 v = *reinterpret_cast<const T2 *>(sJ + c * BT + wj + 16 * q);
+                bv[buf][2 * q] = v.x;
+                bv[buf][2 * q + 1] = v.y;
+            }
+        };
+        auto compute = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) {
+                    if constexpr (KIND == K_L1) {
+                        acc[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
+                    } else if constexpr (KIND == K_SAD) {
+                        part[r][cc] = __usad(av[buf][r], bv[buf][cc], part[r][cc]);
+                    } else if constexpr (KIND == K_SAD16) {
+                        // |a.lo - b.lo| + |a.hi - b.hi| + acc: two columns per instruction
+                        part[r][cc] = __builtin_amdgcn_sad_u16(av[buf][r], bv[buf][cc], part[r][cc]);
+                    } else if constexpr (KIND == K_ZP) {
+                        part[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
+                    } else {
+                        acc[r][cc] = fma(av[buf][r], bv[buf][cc], acc[r][cc]);
+                    }
+                }
+        };
+        // a chunk that closes a layer needs the rows' / columns' 1/ring-size: request them now, they arrive
+        // under the column loop instead of stalling the fold below
+        // (4 x 4 micro-tiles only: the 8 x 8 ones have no registers to spare and load them at the fold)
+        constexpr bool EARLY_INV = (KIND == K_SAD || KIND == K_SAD16) && TR == 4;
+        double vi_[TR], vj_[TC];
+        if constexpr (SEG) {
+            if (EARLY_INV && ends_seg) {
+                gcdouble *invs = ginv + (int64_t)seg * a.npad;
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) vj_[cc] = invs[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+                for (int r = 0; r < TR; ++r) vi_[r] = invs[i0 + wi + 16 * (r >> 1) + (r & 1)];
+            }
+        }
+        load_ops(0, 0);
+        int c = 0;
+        // Eight columns per trip, straight-line: inside the body hipcc's wait-count pass knows how many LDS reads were
+        // issued after the ones a column needs and emits counted waits (lgkmcnt(n)); at a loop head it merges the
+        // back-edge state and waits for everything -- with two columns per trip that drained the read-ahead every 128
+        // instructions (WAIT_ANY 29 % of the wave cycles, profiles/r02a_target).
+        // the scheduling barriers pin "request column c+1, THEN accumulate column c": without
+        // them hipcc sinks the LDS reads below the arithmetic and waits for them at once
+#pragma unroll 1
+        for (; c + 8 <= cvalid; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                load_ops(min(c + u + 1, CH - 1), 1);
+                HSD_PIN_ORDER;
+                compute(0);
+                HSD_PIN_ORDER;
+                load_ops(min(c + u + 2, CH - 1), 0);
+                HSD_PIN_ORDER;
+                compute(1);
+                HSD_PIN_ORDER;
+            }
+        }
+#pragma unroll 1
+        for (; c < cvalid; c += 2) {
+            load_ops(min(c + 1, CH - 1), 1);
+            HSD_PIN_ORDER;
+            compute(0);
+            HSD_PIN_ORDER;
+            if (c + 1 < cvalid) {
+                load_ops(min(c + 2, CH - 1), 0);
+                HSD_PIN_ORDER;
+                compute(1);
+                HSD_PIN_ORDER;
+            }
+        }
+        if constexpr (SEG) {
+            if (ends_seg) {
+                // sum_c |..| / max(n_i, n_j) == sum * min(1/n_i, 1/n_j); empty rings carry inv = 2
+                if constexpr (!EARLY_INV) {
+                    gcdouble *invs = ginv + (int64_t)seg * a.npad;
+#pragma unroll
+                    for (int cc = 0; cc < TC; ++cc) vj_[cc] = invs[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) vi_[r] = invs[i0 + wi + 16 * (r >> 1) + (r & 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < TR; ++r) {
+                    const double vi = vi_[r];
+#pragma unroll
+                    for (int cc = 0; cc < TC; ++cc) {
+                        acc[r][cc] = fma((double)part[r][cc], fmin(vi, vj_[cc]), acc[r][cc]);
+                        part[r][cc] = (T)0;
+                    }
+                }
+            }
+        }
+        if constexpr (!FAST) {
+            __syncthreads();
+            if (k + 1 < nchunks) {
+                const int cn = chunk_col(k + 1);
+                stage_side<T, false, BT, CH>(XI, a.npad, cn, i0, sbase, tid);
+                stage_side<T, false, BT, CH>(XJ, a.npad, cn, j0, sbase + CH * BT, tid);
+            }
+        }
+    }
+    if (a.work && tid == 0) atomicAdd(a.work, work * (unsigned long long)(BT * BT));
+
+    const bool diag = a.sym && ti == tj;
+
+    // ---- epilogue arithmetic ----
+    if constexpr (KIND == K_DOT) {
+        double hj[TC];
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) hj[cc] = gH[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const double hi = gH[i0 + wi + 16 * (r >> 1) + (r & 1)];
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) {
+                if (a.hmode == 0) acc[r][cc] = (a.swap ? hj[cc] : hi) - acc[r][cc];
+                else acc[r][cc] = 0.5 * (hi + hj[cc] - acc[r][cc]);
+            }
+        }
+    }
+    if (gpoint) {
+        double pj[TC];
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) pj[cc] = gpoint[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const double pi = gpoint[i0 + wi + 16 * (r >> 1) + (r & 1)];
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) acc[r][cc] += fabs(pi - pj[cc]);
+        }
+    }
+
+    // ---- stores ----
+    if ((a.dbg & 1) && acc[0][0] != -1.0) {
+        // ablation: no stores
+    } else if (a.tau) {
+        // fused top-k: keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also
+        // serves row j.  Diagonal tiles count each unordered pair once (i < j).
+        gcdouble *tau = (gcdouble *)a.tau;
+        double tj_[TC];
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) {
+            const int64_t j = j0 + wj + 16 * (cc >> 1) + (cc & 1);
+            tj_[cc] = (a.mirror && j < a.j_end) ? tau[j] : -1.0;
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int64_t i = i0 + wi + 16 * (r >> 1) + (r & 1);
+            if (i >= a.i_end) continue;
+            const double ti_ = tau[i];
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) {
+                const int64_t j = j0 + wj + 16 * (cc >> 1) + (cc & 1);
+                if (j >= a.j_end || i == j || (diag && i > j)) continue;
+                const double v = acc[r][cc];
+                if (v <= ti_) {
+                    const int slot = atomicAdd(a.cand_cnt + i, 1);
+                    if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
+                }
+                if (v <= tj_[cc]) {
+                    const int slot = atomicAdd(a.cand_cnt + j, 1);
+                    if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
+                }
+            }
+        }
+    } else if (!diag && i0 + BT <= a.i_end && j0 + BT <= a.j_end) {
+        // interior tile: no masks.  direct: each group of 8 lanes writes one 128-B line of a row
+        gdouble *pd = out + (i0 + wi - a.rbase) * a.ld + (j0 + wj);
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            gdouble *row = pd + (int64_t)(16 * (r >> 1) + (r & 1)) * a.ld;
+#pragma unroll
+            for (int q = 0; q < TC / 2; ++q) store2_full<FAST>(row + 16 * q, acc[r][2 * q], acc[r][2 * q + 1], nt);
+        }
+        if (a.mirror) {
+            // mirrored: same shape with the roles of rows and columns exchanged
+            gdouble *pm = out + (j0 + wj - a.rbase) * a.ld + (i0 + wi);
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) {
+                gdouble *row = pm + (int64_t)(16 * (cc >> 1) + (cc & 1)) * a.ld;
+#pragma unroll
+                for (int q = 0; q < TR / 2; ++q) store2_full<FAST>(row + 16 * q, acc[2 * q][cc], acc[2 * q + 1][cc], nt);
+            }
+        }
+    } else {
+        // edge or diagonal tile: per-element masks in tile-local 32-bit coordinates
+        const int ilim = (int)min((int64_t)BT, a.i_end - i0), jlim = (int)min((int64_t)BT, a.j_end - j0);
+        gdouble *tb = out + (i0 - a.rbase) * a.ld + j0;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            int li = wi + 16 * (r >> 1) + (r & 1);
+            asm volatile("" : "+v"(li) :: "memory");      // masks are formed here, not hoisted en bloc
+            if (li >= ilim) continue;
+            gdouble *row = tb + (int64_t)li * a.ld;
+#pragma unroll
+            for (int q = 0; q < TC / 2; ++q) {
+                const int lj = wj + 16 * q;
+                const bool ok0 = lj < jlim && (!diag || li <= lj);
+                const bool ok1 = lj + 1 < jlim && (!diag || li <= lj + 1);
+                store2<FAST>(row + lj, (diag && li == lj) ? 0.0 : acc[r][2 * q], (diag && li == lj + 1) ? 0.0 : acc[r][2 * q + 1],
+                             ok0, ok1);
+            }
+        }
+        if (a.mirror) {
+            gdouble *mb = out + (j0 - a.rbase) * a.ld + i0;
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) {
+                int lj = wj + 16 * (cc >> 1) + (cc & 1);
+                asm volatile("" : "+v"(lj) :: "memory");
+                if (lj >= jlim) continue;
+                gdouble *row = mb + (int64_t)lj * a.ld;
+#pragma unroll
+                for (int q = 0; q < TR / 2; ++q) {
+                    const int li = wi + 16 * q;
+                    const bool ok0 = li < ilim && (!diag || li < lj);
+                    const bool ok1 = li + 1 < ilim && (!diag || li + 1 < lj);
+                    store2<FAST>(row + li, acc[2 * q][cc], acc[2 * q + 1][cc], ok0, ok1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pair_stream_kernel<KIND, NW>: the same arithmetic as a PERSISTENT workgroup that streams through its tiles.
+//   NW = 4: 128 x 128 tiles as above (wave w owns quadrant (w >> 1, w & 1)), one barrier per operand chunk;
+//   NW = 1: ONE WAVE per workgroup and NO barriers (64 x 64 tiles).
+//
+// Measured on the 4-wave kernel above at BA N = 100k (profiles/r02a_*): with the zero-pad distance down to ~137 words
+// per pair the waves sat in s_waitcnt / s_barrier for 29 % of their cycles and the vector ALU was busy 62 % of the
+// time even with stores disabled -- a wave alone on its SIMD issues one v_sad every ~8.7 cycles against 4.1 when two
+// interleave (tools_dev/ubench_valu.hip), so every stall of one workgroup (tile prologue, per-chunk barrier skew,
+// epilogue) halves the other's rate.  Here a wave owns a whole 64 x 64 tile (8 x 8 pairs per lane, the quadrant of the
+// kernel above), stages its own operand chunks (2-stage ring, one chunk ahead; two ahead across a tile boundary so the
+// epilogue's stores are issued behind the next tile's first loads) and walks a strided share of its XCD's tile run:
+// nothing ever waits for another wave, and the next tile's plan (coordinates, rank-form decision, chunk list) is
+// resolved one tile ahead.  Results are bit-identical to the kernel above (same per-pair operation order).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int stream_chunk_cols(int kind, int nw) {
+    return nw == 1 ? ((kind == K_SAD || kind == K_SAD16) ? 16 : 8) : chunk_cols(kind);
+}
+
+// wait until at most `young` of this wave's vector-memory operations are outstanding (they retire in order, so that
+// means everything older than the `young` newest has landed); a smaller count than the true one only waits longer
+__device__ inline void wait_vm_young(int young) {
+    if (young >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else if (young >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (young >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int KIND, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs a) {
+    using T = typename Elem<KIND>::type;
+    using T2 = typename Vec2<T>::type;
+    constexpr int TR = 8, TC = 8, BT = NW == 4 ? 128 : 64;
+    constexpr bool SEG = (KIND == K_SAD || KIND == K_ZP || KIND == K_SAD16);
+    constexpr int CH = stream_chunk_cols(KIND, NW);
+    constexpr int STAGE = 2 * CH * BT;               // elements per stage: I block, then J block
+    constexpr int LOADS = 2 * CH * BT * (int)sizeof(T) / 1024 / NW;   // 1-KiB direct-to-LDS instructions per chunk and wave
+    static_assert(NW == 1 || NW == 4, "one wave (64 x 64 tile) or four (128 x 128)");
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    T *sbase = reinterpret_cast<T *>(lds_raw);
+    int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
+    int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double *)lds_raw);
+
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int ly = l >> 3, lx = l & 7;
+    const int wi = (NW == 4 ? (w >> 1) * 64 : 0) + 2 * ly, wj = (NW == 4 ? (w & 1) * 64 : 0) + 2 * lx;
+    auto wg_barrier = [&]() __attribute__((always_inline)) {
+        if constexpr (NW > 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    const T *__restrict__ XI = reinterpret_cast<const T *>(a.swap ? a.Y : a.X);
+    const T *__restrict__ XJ = reinterpret_cast<const T *>(a.swap ? a.X : a.Y);
+    gdouble *const out = (gdouble *)a.out;
+    gcdouble *const gH = (gcdouble *)a.H;
+    gcdouble *const ginv = (gcdouble *)a.inv;
+    gcdouble *const gpoint = (gcdouble *)a.point;
+    const bool nt = !(a.dbg & 4);
+
+    // this wave's share: XCD x (workgroups b, b + 8, ... share one) owns a contiguous run of the tile order
+    const int x = blockIdx.x & 7, wx = blockIdx.x >> 3, nwx = gridDim.x >> 3;
+    const int q = a.ntiles >> 3, rr = a.ntiles & 7;
+    const int lo = x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q;
+    const int hi = lo + (x < rr ? q + 1 : q);
+    int t = lo + wx;
+    if (t >= hi) return;
+
+    // lane s keeps the description of layer segment s
+    SegDesc sd{};
+    if constexpr (SEG) {
+        if (l < a.n_seg) sd = a.seg_tab[l];
+        else sd.rank_col0 = -1;
+    }
+    auto stage_chunk = [&](int col, int64_t ri0, int64_t rj0, int st) __attribute__((always_inline)) {
+        // LOADS / 2 instructions per side and wave, each 64 lanes x 16 B = COLS columns x (BT nodes x sizeof(T)) bytes
+        constexpr int LANES_PER_COL = BT * (int)sizeof(T) / 16;
+        constexpr int COLS = 64 / LANES_PER_COL;
+        static_assert((CH / COLS) % NW == 0, "stage instructions must divide over the waves");
+        asm volatile("" ::: "memory");               // no load / store moves across the request: vm_seq below relies on the order
+        const uint32_t dst_lds = lds_base + (uint32_t)(st * STAGE * sizeof(T));
+        const uint32_t lane_off = (uint32_t)(l / LANES_PER_COL) * (uint32_t)(a.npad * sizeof(T)) + 16u * (l % LANES_PER_COL);
+#pragma unroll
+        for (int k = 0; k < CH / COLS / NW; ++k) {
+            const int ins = k * NW + w;
+            glds16_s(reinterpret_cast<uint64_t>(XI + (int64_t)(col + ins * COLS) * a.npad + ri0), lane_off,
+                     dst_lds + (uint32_t)(ins * COLS * BT * sizeof(T)));
+        }
+#pragma unroll
+        for (int k = 0; k < CH / COLS / NW; ++k) {
+            const int ins = k * NW + w;
+            glds16_s(reinterpret_cast<uint64_t>(XJ + (int64_t)(col + ins * COLS) * a.npad + rj0), lane_off,
+                     dst_lds + (uint32_t)((CH * BT + ins * COLS * BT) * sizeof(T)));
+        }
+        asm volatile("" ::: "memory");
+    };
+    // raw ring maxima of the granules a tile touches (lane s: segment s); consumed one tile later
+    auto issue_rmax = [&](int64_t ri0, int64_t rj0, uint32_t (&raw)[4]) __attribute__((always_inline)) {
+        raw[0] = raw[1] = raw[2] = raw[3] = 0;
+        if constexpr (SEG) {
+            if (w == 0 && sd.rank_col0 >= 0) {
+                const uint32_t *rm = a.rmax + (int64_t)l * a.ngran;
+                raw[0] = rm[ri0 >> 6];
+                raw[1] = rm[(ri0 + BT - 1) >> 6];
+                raw[2] = rm[rj0 >> 6];
+                raw[3] = rm[(rj0 + BT - 1) >> 6];
+            }
+        }
+    };
+    // decide bin form / rank form per segment and write the tile's chunk list + its length into list buffer `buf`
+    // (wave 0; the other waves read them behind the next barrier)
+    auto plan = [&](const uint32_t (&raw)[4], int buf) __attribute__((always_inline)) {
+        if constexpr (SEG) {
+            if (w != 0) return;
+            int col0 = sd.bin_col0, words = (l < a.n_seg) ? sd.bin_words : 0;
+            if (sd.rank_col0 >= 0) {
+                const uint32_t R = max(max(raw[0], raw[1]), max(raw[2], raw[3]));
+                const int wr = (KIND == K_SAD16) ? (int)((R + 1) >> 1) : (int)R;
+                if (wr <= sd.rank_cap) { col0 = sd.rank_col0; words = wr; }
+            }
+            const int nch = (words + CH - 1) / CH;
+            int pre = nch;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(pre, o, 64);
+                if (l >= o) pre += up;
+            }
+            int2 *lst = clist + buf * a.list_cap;
+            for (int c = 0; c < nch; ++c)
+                lst[pre - nch + c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+            if (l == 63) nlist[buf] = pre;
+        }
+    };
+    auto planned_chunks = [&](int buf) __attribute__((always_inline)) -> int {
+        if constexpr (SEG) return __builtin_amdgcn_readfirstlane(nlist[buf]);
+        else return (a.dcols_valid + CH - 1) / CH;
+    };
+    auto chunk_col = [&](int buf, int k) __attribute__((always_inline)) -> int {
+        if constexpr (SEG) return __builtin_amdgcn_readfirstlane(clist[buf * a.list_cap + k].x);
+        else return k * CH;
+    };
+
+    // ---- prologue: plan of the first tile, coordinates of the next two ----
+    int ti, tj;
+    tile_from_index(a, t, ti, tj);
+    int64_t i0 = uniform64(a.i_begin + (int64_t)ti * BT), j0 = uniform64(a.j_begin + (int64_t)tj * BT);
+    uint32_t raw[4];
+    issue_rmax(i0, j0, raw);
+    int cur = 0;                                      // list buffer of the tile being computed
+    plan(raw, cur);
+    if constexpr (SEG) { if constexpr (NW > 1) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    int n0 = planned_chunks(cur);
+    int t1 = t + nwx, t2 = t + 2 * nwx;
+    int ti1 = 0, tj1 = 0, ti2 = 0, tj2 = 0;
+    if (t1 < hi) tile_from_index(a, t1, ti1, tj1);
+    if (t2 < hi) tile_from_index(a, t2, ti2, tj2);
+    int64_t i1 = uniform64(a.i_begin + (int64_t)ti1 * BT), j1 = uniform64(a.j_begin + (int64_t)tj1 * BT);
+    uint32_t raw1[4];
+    if (t1 < hi) issue_rmax(i1, j1, raw1);
+
+    int vm_seq = 0;                                   // vector-memory operations issued so far (lower bound: masked stores are not counted)
+    int seq_of_stage[2] = {0, 0};                     // vm_seq right after the loads of the chunk that sits in each LDS stage
+    int st = 0;                                       // LDS stage of the next chunk to be computed
+    int ahead = 0;                                    // chunks of the current tile whose loads are already issued
+    if (n0 > 0) { stage_chunk(chunk_col(cur, 0), i0, j0, 0); vm_seq += LOADS; seq_of_stage[0] = vm_seq; ahead = 1; }
+    if (n0 > 1) { stage_chunk(chunk_col(cur, 1), i0, j0, 1); vm_seq += LOADS; seq_of_stage[1] = vm_seq; ahead = 2; }
+    unsigned long long work = 0;
 
     while (true) {
         double acc[TR][TC];
@@ -266,53 +763,62 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
 #pragma unroll
                 for (int c = 0; c < TC; ++c) part[r][c] = (T)0;
         }
-        int seg = 0;
-        uint32_t ni[TR], nj[TC];                     // K_RAT: ring sizes of this lane's rows / columns in the current layer
-        for (int k = 0; k < nchunks; ++k) {
-            if constexpr (KIND == K_RAT) {
-                if (k * CH == seg * a.seg_stride) {
-                    gcu32 *nr = (gcu32 *)a.nring + (int64_t)seg * a.npad;
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) ni[r] = nr[i0 + wi + 16 * (r >> 1) + (r & 1)];
-#pragma unroll
-                    for (int cc = 0; cc < TC; ++cc) nj[cc] = nr[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
-                }
-            }
-            if constexpr (FAST) {
-                // raw barrier + counted wait: a __syncthreads() here would also drain the result
-                // stores of the previous tile (its fence waits vmcnt(0))
-                wait_vm_except(k == 0 ? stores_behind : 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+        // the next tile's plan: its ring maxima were requested one tile ago
+        const bool has1 = t1 < hi;
+        int n1 = 0;
+        if (has1) plan(raw1, cur ^ 1);
+        wg_barrier();                                 // list of the next tile visible; every wave is done with the previous tile's LDS
+        if (has1) n1 = planned_chunks(cur ^ 1);
+        // ... and the maxima of the tile after it are requested now
+        const bool has2 = t2 < hi;
+        const int64_t i2 = uniform64(a.i_begin + (int64_t)ti2 * BT), j2 = uniform64(a.j_begin + (int64_t)tj2 * BT);
+        if (has2) issue_rmax(i2, j2, raw1);            // (not counted in vm_seq: only operations that are certainly issued are)
+        int ahead1 = 0;                               // chunks of the NEXT tile already requested
+
+        for (int k = 0; k < n0; ++k) {
+            int cvalid, seg = 0;
+            bool ends_seg = false;
+            if constexpr (SEG) {
+                const int meta = __builtin_amdgcn_readfirstlane(clist[cur * a.list_cap + k].y);
+                cvalid = meta & 0xff;
+                ends_seg = (meta & 0x100) != 0;
+                seg = meta >> 16;
             } else {
-                __syncthreads();
+                cvalid = min(CH, a.dcols_valid - k * CH);
             }
-            const T *sI = sbase + (size_t)(FAST ? (k & 1) : 0) * 2 * CH * BT;
+            work += (unsigned)cvalid;
+            if (a.dbg & 2) cvalid = 0;
+            // chunk k has landed once everything older than the operations issued after its loads has retired
+            wait_vm_young(__builtin_amdgcn_readfirstlane(vm_seq - (st ? seq_of_stage[1] : seq_of_stage[0])));
+            if constexpr (NW > 1) wg_barrier();           // every wave's part of chunk k has landed, and chunk k - 1 is consumed
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const T *sI = sbase + st * STAGE;
             const T *sJ = sI + CH * BT;
-            if constexpr (FAST) {
-                if (k > 0 && k + 1 < nchunks) {
-                    T *nI = sbase + (size_t)((k + 1) & 1) * 2 * CH * BT;
-                    stage_side<T, true, BT, CH>(XI, a.npad, (k + 1) * CH, i0, nI, tid);
-                    stage_side<T, true, BT, CH>(XJ, a.npad, (k + 1) * CH, j0, nI + CH * BT, tid);
+            // the other stage is free (its chunk was consumed in the previous iteration): request the chunk after next
+            // of this tile, or -- at the end of the tile -- the first chunks of the next one
+            if (k >= 1 || ahead < 2) {
+                // (k == 0 with two chunks in flight: nothing to request, both stages are taken)
+                if (ahead < n0) {
+                    stage_chunk(chunk_col(cur, ahead), i0, j0, st ^ 1);
+                    vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ++ahead;
+                } else if (ahead1 < n1 && ahead1 < 1) {
+                    stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st ^ 1);
+                    vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 1;
                 }
             }
-            // columns of this chunk that carry data (the tail of a segment is zero padding)
-            const int cvalid = (a.dbg & 2) ? 0 : min(CH, (SEG ? a.seg_valid : a.dcols_valid) - (k * CH - (SEG ? seg * a.seg_stride : 0)));
-            // operands are double-buffered in registers: the LDS reads of column c+1 are in flight
-            // while column c is being accumulated
             T av[2][TR], bv[2][TC];
             auto load_ops = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
-                for (int q = 0; q < TR / 2; ++q) {
-                    const T2 v = *reinterpret_cast<const T2 *>(sI + c * BT + wi + 16 * q);
-                    av[buf][2 * q] = v.x;
-                    av[buf][2 * q + 1] = v.y;
+                for (int qq = 0; qq < TR / 2; ++qq) {
+                    const T2 v = *reinterpret_cast<const T2 *>(sI + c * BT + wi + 16 * qq);
+                    av[buf][2 * qq] = v.x;
+                    av[buf][2 * qq + 1] = v.y;
                 }
 #pragma unroll
-                for (int q = 0; q < TC / 2; ++q) {
-                    const T2 v = *reinterpret_cast<const T2 *>(sJ + c * BT + wj + 16 * q);
-                    bv[buf][2 * q] = v.x;
-                    bv[buf][2 * q + 1] = v.y;
+                for (int qq = 0; qq < TC / 2; ++qq) {
+                    const T2 v = *reinterpret_cast<const T2 *>(sJ + c * BT + wj + 16 * qq);
+                    bv[buf][2 * qq] = v.x;
+                    bv[buf][2 * qq + 1] = v.y;
                 }
             };
             auto compute = [&](int buf) __attribute__((always_inline)) {
@@ -320,44 +826,31 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
                     for (int cc = 0; cc < TC; ++cc) {
-                        if constexpr (KIND == K_L1) {
-                            acc[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
-                        } else if constexpr (KIND == K_SAD) {
-                            part[r][cc] = __usad(av[buf][r], bv[buf][cc], part[r][cc]);
-                        } else if constexpr (KIND == K_RAT) {
-                            // |cc_i/n_i - cc_j/n_j| * n_i n_j = |cc_i n_j - cc_j n_i|: exact in uint32
-                            part[r][cc] = __usad(__umul24(av[buf][r], nj[cc]), __umul24(bv[buf][cc], ni[r]), part[r][cc]);
-                        } else if constexpr (KIND == K_SAD16) {
-                            // |a.lo - b.lo| + |a.hi - b.hi| + acc: two columns per instruction
-                            part[r][cc] = __builtin_amdgcn_sad_u16(av[buf][r], bv[buf][cc], part[r][cc]);
-                        } else if constexpr (KIND == K_ZP) {
-                            part[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
-                        } else {
-                            acc[r][cc] = fma(av[buf][r], bv[buf][cc], acc[r][cc]);
-                        }
+                        if constexpr (KIND == K_L1) acc[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
+                        else if constexpr (KIND == K_SAD) part[r][cc] = __usad(av[buf][r], bv[buf][cc], part[r][cc]);
+                        else if constexpr (KIND == K_SAD16) part[r][cc] = __builtin_amdgcn_sad_u16(av[buf][r], bv[buf][cc], part[r][cc]);
+                        else if constexpr (KIND == K_ZP) part[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
+                        else acc[r][cc] = fma(av[buf][r], bv[buf][cc], acc[r][cc]);
                     }
             };
-            // a chunk that closes a layer needs the rows' / columns' 1/ring-size: request them now, they arrive
-            // under the column loop instead of stalling the fold below
-            // (4 x 4 micro-tiles only: the 8 x 8 ones have no registers to spare and load them at the fold)
-            constexpr bool EARLY_INV = (KIND == K_SAD || KIND == K_SAD16) && TR == 4;
-            bool ends_seg = false;
-            double vi_[TR], vj_[TC];
-            if constexpr (SEG) {
-                ends_seg = (k + 1) * CH == (seg + 1) * a.seg_stride;
-                if (EARLY_INV && ends_seg) {
-                    gcdouble *invs = ginv + (int64_t)seg * a.npad;
+            load_ops(0, 0);
+            int c = 0;
+#pragma unroll 1
+            for (; c + 8 <= cvalid; c += 8) {        // straight-line body: counted LDS waits (see pair_kernel)
 #pragma unroll
-                    for (int cc = 0; cc < TC; ++cc) vj_[cc] = invs[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) vi_[r] = invs[i0 + wi + 16 * (r >> 1) + (r & 1)];
+                for (int u = 0; u < 8; u += 2) {
+                    load_ops(min(c + u + 1, CH - 1), 1);
+                    HSD_PIN_ORDER;
+                    compute(0);
+                    HSD_PIN_ORDER;
+                    load_ops(min(c + u + 2, CH - 1), 0);
+                    HSD_PIN_ORDER;
+                    compute(1);
+                    HSD_PIN_ORDER;
                 }
             }
-            load_ops(0, 0);
 #pragma unroll 1
-            for (int c = 0; c < cvalid; c += 2) {
-                // the scheduling barriers pin "request column c+1, THEN accumulate column c": without
-                // them hipcc sinks the LDS reads below the arithmetic and waits for them at once
+            for (; c < cvalid; c += 2) {
                 load_ops(min(c + 1, CH - 1), 1);
                 HSD_PIN_ORDER;
                 compute(0);
@@ -371,158 +864,106 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
             }
             if constexpr (SEG) {
                 if (ends_seg) {
-                    // sum_c |..| / max(n_i, n_j) == sum * min(1/n_i, 1/n_j); empty rings carry inv = 2
-                    if constexpr (!EARLY_INV) {
-                        gcdouble *invs = ginv + (int64_t)seg * a.npad;
+                    gcdouble *invs = ginv + (int64_t)seg * a.npad;
+                    double vi_[TR], vj_[TC];
 #pragma unroll
-                        for (int cc = 0; cc < TC; ++cc) vj_[cc] = invs[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+                    for (int cc = 0; cc < TC; ++cc) vj_[cc] = invs[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
-                        for (int r = 0; r < TR; ++r) vi_[r] = invs[i0 + wi + 16 * (r >> 1) + (r & 1)];
-                    }
+                    for (int r = 0; r < TR; ++r) vi_[r] = invs[i0 + wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                     for (int r = 0; r < TR; ++r) {
                         const double vi = vi_[r];
 #pragma unroll
                         for (int cc = 0; cc < TC; ++cc) {
-                            if constexpr (KIND == K_RAT) acc[r][cc] = fma((double)part[r][cc], vi * vj_[cc], acc[r][cc]);   // / (n_i n_j)
-                            else acc[r][cc] = fma((double)part[r][cc], fmin(vi, vj_[cc]), acc[r][cc]);
+                            acc[r][cc] = fma((double)part[r][cc], fmin(vi, vj_[cc]), acc[r][cc]);
                             part[r][cc] = (T)0;
                         }
                     }
-                    ++seg;
                 }
             }
-            if constexpr (!FAST) {
-                __syncthreads();
-                if (k + 1 < nchunks) {
-                    stage_side<T, false, BT, CH>(XI, a.npad, (k + 1) * CH, i0, sbase, tid);
-                    stage_side<T, false, BT, CH>(XJ, a.npad, (k + 1) * CH, j0, sbase + CH * BT, tid);
-                }
-            }
+            st ^= 1;
+        }
+        // the second chunk of the next tile goes out BEFORE this tile's stores: its loads then do not queue behind them
+        if constexpr (NW > 1) wg_barrier();           // the stage of the last chunk is free only when every wave has consumed it
+        if (ahead1 == 0 && n1 > 0) {
+            stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st);
+            vm_seq += LOADS; seq_of_stage[st] = vm_seq; ahead1 = 1;
+        }
+        if (ahead1 == 1 && n1 > 1) {
+            stage_chunk(chunk_col(cur ^ 1, 1), i1, j1, st ^ 1);
+            vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 2;
         }
 
-        // ---- next tile: request its operands BEFORE this tile's results are stored ----
-        const int tn = t + (int)gridDim.x;
-        const bool has_next = tn < a.ntiles;
         const bool diag = a.sym && ti == tj;
-        const int64_t ci0 = i0, cj0 = j0;            // coordinates of the tile being stored
-        if (has_next) {
-            decode_tile(a, tn, ti, tj);
-            i0 = a.i_begin + (int64_t)ti * BT;
-            j0 = a.j_begin + (int64_t)tj * BT;
-            if constexpr (FAST) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();        // every wave is done reading both LDS stages
-            } else {
-                __syncthreads();
-            }
-            request(i0, j0);
-        }
-
         // ---- epilogue arithmetic ----
         if constexpr (KIND == K_DOT) {
             double hj[TC];
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) hj[cc] = gH[cj0 + wj + 16 * (cc >> 1) + (cc & 1)];
+            for (int cc = 0; cc < TC; ++cc) hj[cc] = gH[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const double hi = gH[ci0 + wi + 16 * (r >> 1) + (r & 1)];
+                const double hi_ = gH[i0 + wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
-                    if (a.hmode == 0) acc[r][cc] = (a.swap ? hj[cc] : hi) - acc[r][cc];
-                    else acc[r][cc] = 0.5 * (hi + hj[cc] - acc[r][cc]);
+                    if (a.hmode == 0) acc[r][cc] = (a.swap ? hj[cc] : hi_) - acc[r][cc];
+                    else acc[r][cc] = 0.5 * (hi_ + hj[cc] - acc[r][cc]);
                 }
             }
         }
         if (gpoint) {
             double pj[TC];
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) pj[cc] = gpoint[cj0 + wj + 16 * (cc >> 1) + (cc & 1)];
+            for (int cc = 0; cc < TC; ++cc) pj[cc] = gpoint[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const double pi = gpoint[ci0 + wi + 16 * (r >> 1) + (r & 1)];
+                const double pi = gpoint[i0 + wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) acc[r][cc] += fabs(pi - pj[cc]);
             }
         }
-
         // ---- stores ----
-        stores_behind = 0;                           // unknown or none: the next wait drains everything
+        asm volatile("" ::: "memory");
         if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
-        } else if (a.tau) {
-            // fused top-k: keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also
-            // serves row j.  Diagonal tiles count each unordered pair once (i < j).
-            gcdouble *tau = (gcdouble *)a.tau;
-            double tj_[TC];
-#pragma unroll
-            for (int cc = 0; cc < TC; ++cc) {
-                const int64_t j = cj0 + wj + 16 * (cc >> 1) + (cc & 1);
-                tj_[cc] = (a.mirror && j < a.j_end) ? tau[j] : -1.0;
-            }
-#pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                const int64_t i = ci0 + wi + 16 * (r >> 1) + (r & 1);
-                if (i >= a.i_end) continue;
-                const double ti_ = tau[i];
-#pragma unroll
-                for (int cc = 0; cc < TC; ++cc) {
-                    const int64_t j = cj0 + wj + 16 * (cc >> 1) + (cc & 1);
-                    if (j >= a.j_end || i == j || (diag && i > j)) continue;
-                    const double v = acc[r][cc];
-                    if (v <= ti_) {
-                        const int slot = atomicAdd(a.cand_cnt + i, 1);
-                        if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
-                    }
-                    if (v <= tj_[cc]) {
-                        const int slot = atomicAdd(a.cand_cnt + j, 1);
-                        if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
-                    }
-                }
-            }
-        } else if (!diag && ci0 + BT <= a.i_end && cj0 + BT <= a.j_end) {
-            // interior tile: no masks.  direct: each group of 8 lanes writes one 128-B line of a row
-            gdouble *pd = out + (ci0 + wi - a.rbase) * a.ld + (cj0 + wj);
+        } else if (!diag && i0 + BT <= a.i_end && j0 + BT <= a.j_end) {
+            gdouble *pd = out + (i0 + wi - a.rbase) * a.ld + (j0 + wj);
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 gdouble *row = pd + (int64_t)(16 * (r >> 1) + (r & 1)) * a.ld;
 #pragma unroll
-                for (int q = 0; q < TC / 2; ++q) store2_full<FAST>(row + 16 * q, acc[r][2 * q], acc[r][2 * q + 1], nt);
+                for (int qq = 0; qq < TC / 2; ++qq) store2_full<true>(row + 16 * qq, acc[r][2 * qq], acc[r][2 * qq + 1], nt);
             }
-            stores_behind = TR * TC / 2;
+            vm_seq += TR * TC / 2;
             if (a.mirror) {
-                // mirrored: same shape with the roles of rows and columns exchanged
-                gdouble *pm = out + (cj0 + wj - a.rbase) * a.ld + (ci0 + wi);
+                gdouble *pm = out + (j0 + wj - a.rbase) * a.ld + (i0 + wi);
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
                     gdouble *row = pm + (int64_t)(16 * (cc >> 1) + (cc & 1)) * a.ld;
 #pragma unroll
-                    for (int q = 0; q < TR / 2; ++q) store2_full<FAST>(row + 16 * q, acc[2 * q][cc], acc[2 * q + 1][cc], nt);
+                    for (int qq = 0; qq < TR / 2; ++qq) store2_full<true>(row + 16 * qq, acc[2 * qq][cc], acc[2 * qq + 1][cc], nt);
                 }
-                stores_behind = TR * TC;
+                vm_seq += TR * TC / 2;
             }
-            if (!FAST) stores_behind = 0;
         } else {
-            // edge or diagonal tile: per-element masks in tile-local 32-bit coordinates
-            const int ilim = (int)min((int64_t)BT, a.i_end - ci0), jlim = (int)min((int64_t)BT, a.j_end - cj0);
-            gdouble *tb = out + (ci0 - a.rbase) * a.ld + cj0;
+            // edge or diagonal tile: per-element masks (these stores are not counted in vm_seq: a lower bound is safe)
+            const int ilim = (int)min((int64_t)BT, a.i_end - i0), jlim = (int)min((int64_t)BT, a.j_end - j0);
+            gdouble *tb = out + (i0 - a.rbase) * a.ld + j0;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 int li = wi + 16 * (r >> 1) + (r & 1);
-                asm volatile("" : "+v"(li) :: "memory");      // masks are formed here, not hoisted en bloc
+                asm volatile("" : "+v"(li) :: "memory");
                 if (li >= ilim) continue;
                 gdouble *row = tb + (int64_t)li * a.ld;
 #pragma unroll
-                for (int q = 0; q < TC / 2; ++q) {
-                    const int lj = wj + 16 * q;
+                for (int qq = 0; qq < TC / 2; ++qq) {
+                    const int lj = wj + 16 * qq;
                     const bool ok0 = lj < jlim && (!diag || li <= lj);
                     const bool ok1 = lj + 1 < jlim && (!diag || li <= lj + 1);
-                    store2<FAST>(row + lj, (diag && li == lj) ? 0.0 : acc[r][2 * q], (diag && li == lj + 1) ? 0.0 : acc[r][2 * q + 1],
-                                 ok0, ok1);
+                    store2<true>(row + lj, (diag && li == lj) ? 0.0 : acc[r][2 * qq], (diag && li == lj + 1) ? 0.0 : acc[r][2 * qq + 1], ok0, ok1);
                 }
             }
             if (a.mirror) {
-                gdouble *mb = out + (cj0 - a.rbase) * a.ld + ci0;
+                gdouble *mb = out + (j0 - a.rbase) * a.ld + i0;
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
                     int lj = wj + 16 * (cc >> 1) + (cc & 1);
@@ -530,18 +971,24 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
                     if (lj >= jlim) continue;
                     gdouble *row = mb + (int64_t)lj * a.ld;
 #pragma unroll
-                    for (int q = 0; q < TR / 2; ++q) {
-                        const int li = wi + 16 * q;
+                    for (int qq = 0; qq < TR / 2; ++qq) {
+                        const int li = wi + 16 * qq;
                         const bool ok0 = li < ilim && (!diag || li < lj);
                         const bool ok1 = li + 1 < ilim && (!diag || li + 1 < lj);
-                        store2<FAST>(row + li, acc[2 * q][cc], acc[2 * q + 1][cc], ok0, ok1);
+                        store2<true>(row + li, acc[2 * qq][cc], acc[2 * qq + 1][cc], ok0, ok1);
                     }
                 }
             }
         }
-        if (!has_next) break;
-        t = tn;
+        if (!has1) break;
+        // ---- rotate: next tile becomes current ----
+        t = t1; t1 = t2; t2 += nwx;
+        ti = ti1; tj = tj1; ti1 = ti2; tj1 = tj2;
+        i0 = i1; j0 = j1; i1 = i2; j1 = j2;
+        n0 = n1; cur ^= 1; ahead = ahead1;
+        if (t2 < hi) tile_from_index(a, t2, ti2, tj2);
     }
+    if (a.work && threadIdx.x == 0) atomicAdd(a.work, work * (unsigned long long)(BT * BT));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -583,40 +1030,13 @@ __global__ void prep_l1_kernel(PrepArgs p, double *__restrict__ X, int col_begin
     }
 }
 
-// W1 on raw samples in exact integers: |cc_i/n_i - cc_j/n_j| = |cc_i n_j - cc_j n_i| / (n_i n_j), so the
-// operand columns are uint32 cumulative counts x bin width, and the ring sizes ride along.
-__global__ void prep_rat_kernel(PrepArgs p, uint32_t *__restrict__ X, uint32_t *__restrict__ nring, double *__restrict__ inv,
-                                double *__restrict__ point, int seg_stride) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = p.layer_lo + blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    if (k == 0) {
-        point[i] = p.support[p.node_bin[i]];
-        return;
-    }
-    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
-    const int s = k - first;
-    uint32_t tot = 0;
-    for (int b = 0; b < p.B; ++b) tot += c[b];
-    if (tot == 0) atomicOr(p.flag, 1);
-    nring[(int64_t)s * p.npad + i] = tot;
-    inv[(int64_t)s * p.npad + i] = tot ? 1.0 / (double)tot : 0.0;
-    const int64_t cb = (int64_t)s * seg_stride;
-    uint32_t cc = 0;
-    for (int b = 0; b + 1 < p.B; ++b) {
-        cc += c[b];
-        X[(cb + b) * p.npad + i] = cc * (uint32_t)(p.support[b + 1] - p.support[b]);
-    }
-}
-
 // zero-pad alignment (tools/metrics.py:26-28): both samples padded with zeros to max(n_i, n_j),
 // so with tail counts T[b] = #members with value > s[b]:
 //   W1 = 1/max(n_i,n_j) * ( |n_i - n_j| * s[0] + sum_b |T_i[b] - T_j[b]| * (s[b+1]-s[b]) )
 // columns of layer k>=1: [ n*s[0], T[0]*d[0], ..., T[B-2]*d[B-2] ]  (B columns), inv = 1/n (2 if empty)
 template <typename T>
 __global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict__ inv, double *__restrict__ point,
-                               const int *__restrict__ seg_begin) {
+                               const int *__restrict__ seg_begin, uint32_t *__restrict__ ntot /* [n_seg][npad] ring sizes */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int k = p.layer_lo + blockIdx.y;
     if (i >= p.n) return;
@@ -630,6 +1050,7 @@ __global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict
     uint32_t tot = 0;
     for (int b = 0; b < p.B; ++b) tot += c[b];
     inv[(int64_t)s * p.npad + i] = tot ? 1.0 / (double)tot : 2.0;
+    ntot[(int64_t)s * p.npad + i] = tot;
     const int64_t cb = seg_begin[s];
     X[cb * p.npad + i] = (T)((double)tot * p.support[0]);
     uint32_t tail = tot;
@@ -637,6 +1058,45 @@ __global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict
         tail -= c[b];
         X[(cb + 1 + b) * p.npad + i] = (T)((double)tail * (p.support[b + 1] - p.support[b]));
     }
+}
+
+// Rank form of a zero-pad layer (SegDesc): word w of node i holds the (2w)-th and (2w+1)-th largest member values of
+// the ring (PACK: two uint16 per word; else one uint32 per word), zeros beyond the ring's size.  The histogram is
+// walked from the top bin down; only the first `cap` words are kept (longer rings use the bin form).
+template <bool PACK>
+__global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_col0, const int *__restrict__ seg_rank_cap,
+                                 uint32_t *__restrict__ X) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
+    const int sgi = blockIdx.y;
+    const int k = first + sgi;
+    if (i >= p.n || seg_rank_col0[sgi] < 0) return;
+    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
+    const int cap = seg_rank_cap[sgi];
+    uint32_t *col = X + (int64_t)seg_rank_col0[sgi] * p.npad + i;
+    const int want = PACK ? 2 * cap : cap;           // values to emit
+    int r = 0;
+    uint32_t lo = 0;
+    for (int b = p.B - 1; b >= 0 && r < want; --b) {
+        const uint32_t v = (uint32_t)p.support[b];
+        for (uint32_t m = c[b]; m > 0 && r < want; --m, ++r) {
+            if (PACK) {
+                if (r & 1) col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16);
+                else lo = v;
+            } else {
+                col[(int64_t)r * p.npad] = v;
+            }
+        }
+    }
+    if (PACK && (r & 1)) col[(int64_t)(r >> 1) * p.npad] = lo;      // odd count: upper half stays 0
+}
+
+// rmax[s][g] = largest ring size of layer segment s within the 64-node granule g
+__global__ void granule_max_kernel(const uint32_t *__restrict__ ntot, int64_t npad, int ngran, uint32_t *__restrict__ rmax) {
+    const int g = blockIdx.x, sgi = blockIdx.y;
+    uint32_t v = ntot[(int64_t)sgi * npad + (int64_t)g * 64 + threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_down((int)v, o, 64));
+    if (threadIdx.x == 0) rmax[(int64_t)sgi * ngran + g] = v;
 }
 
 // KL: P = (c + alpha) / (n + alpha B), LP = log P, H = sum P LP.  symmetric: X = [P ; LP], Y = [LP ; P].
@@ -700,23 +1160,15 @@ __global__ void sort_counts_kernel(const uint32_t *__restrict__ in, uint32_t *__
 template <int KIND, bool FAST, int TR>
 hipError_t launch_pair(hsd_ctx *ctx, const PairArgs &a, int grid, hipStream_t stream) {
     auto kern = pair_kernel<KIND, FAST, TR>;
-    constexpr size_t lds = (size_t)2 * 2 * chunk_cols(KIND) * (16 * TR) * sizeof(typename Elem<KIND>::type);   // 2 stages x (I, J)
-    static bool attr_set = false;
-    if (!attr_set) {
+    // 2 stages x (I, J) operand chunks, then (segmented kinds) the tile's chunk list + its length
+    const size_t lds = (size_t)2 * 2 * chunk_cols(KIND) * (16 * TR) * sizeof(typename Elem<KIND>::type) + (size_t)a.list_cap * sizeof(int2) + 16;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_lds = lds;
     }
-    // HSD_PERSIST=1: resident-sized grid, every workgroup walks several tiles
-    static int per_cu = 0;
-    if (!per_cu) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NT, lds) != hipSuccess || nb < 1) nb = 1;
-        per_cu = nb;
-    }
-    const char *pe = getenv("HSD_PERSIST");
-    const bool persist = pe ? atoi(pe) != 0 : false;
-    if (persist) grid = std::min(grid, std::max(8, per_cu * ctx->prop.multiProcessorCount / 8 * 8));
+    (void)ctx;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, a);
     return hipGetLastError();
 }
@@ -736,34 +1188,95 @@ int tile_edge(const hsd_ctx *ctx) {
     if (ctx->mode == PAIR_ZP_F64) return 64;      // fallback kind is built for 64 x 64 only
     const char *e = getenv("HSD_TILE");
     if (e) return atoi(e) == 128 ? 128 : 64;
-    if ((ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16) && ctx->dcols <= 128) return 64;
-    if (ctx->mode == PAIR_RAT_U32) return 64;      // 4 x 4 pairs per lane: 4 waves per SIMD keep the 32-bit VALU fed
+    if ((ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16) && ctx->seg_begin[ctx->n_seg] <= 128) return 64;   // padded bin-form words
     return 128;
 }
 
-// Explicit tile order, cached per region shape: S x S groups of tiles (row-major inside a group and
-// over the groups).  nullptr (formula order in the kernel) when disabled or on allocation failure.
+// Explicit tile order, cached per region shape: S x S groups of tiles (row-major inside a group).  The kernels give
+// XCD x the x-th eighth of the list, so the groups are dealt to the XCDs round-robin (XCD x gets groups x, x + 8, ...)
+// and each eighth holds one XCD's groups: every XCD then walks a sample of the WHOLE pair space.  With row-major group
+// order one XCD owned the top rows and another the bottom-right corner -- equal work while every tile costs the same,
+// but with the rank form a tile of two young (low-degree) node blocks costs a fraction of a hub tile, and the XCD that
+// owned the cheap corner idled (wave occupancy 73-84 % at BA N = 100k, profiles/r02b).  HSD_XCD_DEAL=0: plain order.
+// nullptr (formula order in the kernel) when disabled or on allocation failure.
 const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym) {
     const char *e = getenv("HSD_SUPERTILE");
     const int S = e ? atoi(e) : 8;
     if (S <= 1) return nullptr;
+    const char *ed = getenv("HSD_XCD_DEAL");
+    const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
+    const int key = S + (deal << 16);
     for (const auto &c : ctx->tile_lists)
-        if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == S) return reinterpret_cast<const int2 *>(c.d);
+        if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == key) return reinterpret_cast<const int2 *>(c.d);
     std::vector<int2> order;
     order.reserve(sym ? (size_t)tiles_i * (tiles_i + 1) / 2 : (size_t)tiles_i * tiles_j);
+    std::vector<size_t> group_begin;
     for (int sr = 0; sr < tiles_i; sr += S)
-        for (int sc = sym ? sr : 0; sc < tiles_j; sc += S)
+        for (int sc = sym ? sr : 0; sc < tiles_j; sc += S) {
+            group_begin.push_back(order.size());
             for (int ti = sr; ti < std::min(sr + S, tiles_i); ++ti)
                 for (int tj = std::max(sc, sym ? ti : 0); tj < std::min(sc + S, tiles_j); ++tj) order.push_back(make_int2(ti, tj));
+        }
+    group_begin.push_back(order.size());
+    if (deal && group_begin.size() > 9) {
+        std::vector<int2> dealt;
+        dealt.reserve(order.size());
+        const size_t ng = group_begin.size() - 1;
+        for (size_t x = 0; x < 8; ++x)
+            for (size_t g = x; g < ng; g += 8) dealt.insert(dealt.end(), order.begin() + (long)group_begin[g], order.begin() + (long)group_begin[g + 1]);
+        order.swap(dealt);
+    }
     void *d = nullptr;
     if (hipMalloc(&d, order.size() * sizeof(int2)) != hipSuccess) return nullptr;
     if (hipMemcpy(d, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
     if (ctx->tile_lists.size() >= 8) { (void)hipFree(ctx->tile_lists.front().d); ctx->tile_lists.erase(ctx->tile_lists.begin()); }
-    ctx->tile_lists.push_back({tiles_i, tiles_j, sym, S, d});
+    ctx->tile_lists.push_back({tiles_i, tiles_j, sym, key, d});
     return reinterpret_cast<const int2 *>(d);
 }
 
+template <int KIND, int NW>
+hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
+    auto kern = pair_stream_kernel<KIND, NW>;
+    constexpr int CH = stream_chunk_cols(KIND, NW);
+    constexpr int BT = NW == 4 ? 128 : 64;
+    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    // persistent grid: two waves per SIMD on every CU (HSD_WAVES_PER_CU overrides), a multiple of 8 so that every XCD
+    // gets the same number of workgroups; a workgroup with no tile in its XCD's run exits at once
+    static int per_cu = 0;
+    if (!per_cu) {
+        const char *e = getenv("HSD_WAVES_PER_CU");
+        per_cu = e ? std::max(NW, atoi(e)) : 8;
+    }
+    const int64_t resident = (int64_t)(per_cu / NW) * ctx->prop.multiProcessorCount / 8 * 8;
+    const int grid = (int)std::min<int64_t>(resident, round_up(a.ntiles, 8));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
+    return hipGetLastError();
+}
+
+// The persistent kernels take every region whose operand slices and output rows are 16-byte aligned (direct-to-LDS
+// loads, vector stores), except the fused k-nearest consumer and the fp64 zero-pad fallback (its two fp64 accumulator
+// sets do not fit 8 x 8 pairs per lane).  HSD_STREAM=0: the one-tile-per-workgroup kernel; 1: one wave per workgroup
+// (64 x 64 tiles); 4: four waves (128 x 128 tiles).
+int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
+    const char *ew = getenv("HSD_STREAM");
+    const int nw = ew ? atoi(ew) : 0;
+    if (nw != 1 && nw != 4) return 0;
+    if (getenv("HSD_TILE")) return 0;               // an explicit tile shape asks for the one-tile kernel
+    if (a.tau || ctx->mode == PAIR_ZP_F64) return 0;
+    const bool aligned = (a.i_begin % 4 == 0) && (a.j_begin % 4 == 0) && (a.npad % 4 == 0) && (a.ld % 2 == 0) &&
+                         (reinterpret_cast<uintptr_t>(a.out) % 16 == 0);
+    return aligned ? nw : 0;
+}
+
 int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
+    const int nw = stream_waves(ctx, a);
+    if (nw) BT = nw == 4 ? 128 : 64;
     a.tiles_i = (int)((a.i_end - a.i_begin + BT - 1) / BT);
     a.tiles_j = (int)((a.j_end - a.j_begin + BT - 1) / BT);
     if (a.tiles_i <= 0 || a.tiles_j <= 0) return HSD_OK;
@@ -773,10 +1286,21 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
     const int g = (int)nb;
     a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym);
     hipError_t e;
+    if (nw) {
+        switch (ctx->mode) {
+            case PAIR_L1_F64: e = nw == 4 ? launch_stream<K_L1, 4>(ctx, a, stream) : launch_stream<K_L1, 1>(ctx, a, stream); break;
+            case PAIR_SAD_U32: e = nw == 4 ? launch_stream<K_SAD, 4>(ctx, a, stream) : launch_stream<K_SAD, 1>(ctx, a, stream); break;
+            case PAIR_SAD_U16: e = nw == 4 ? launch_stream<K_SAD16, 4>(ctx, a, stream) : launch_stream<K_SAD16, 1>(ctx, a, stream); break;
+            case PAIR_KL:
+            case PAIR_SKL: e = nw == 4 ? launch_stream<K_DOT, 4>(ctx, a, stream) : launch_stream<K_DOT, 1>(ctx, a, stream); break;
+            default: return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
+        }
+        if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
+        return HSD_OK;
+    }
     switch (ctx->mode) {
         case PAIR_L1_F64: e = BT == 128 ? launch_kind<K_L1, 8>(ctx, a, g, stream) : launch_kind<K_L1, 4>(ctx, a, g, stream); break;
         case PAIR_SAD_U32: e = BT == 128 ? launch_kind<K_SAD, 8>(ctx, a, g, stream) : launch_kind<K_SAD, 4>(ctx, a, g, stream); break;
-        case PAIR_RAT_U32: e = BT == 128 ? launch_kind<K_RAT, 8>(ctx, a, g, stream) : launch_kind<K_RAT, 4>(ctx, a, g, stream); break;
         case PAIR_SAD_U16: e = BT == 128 ? launch_kind<K_SAD16, 8>(ctx, a, g, stream) : launch_kind<K_SAD16, 4>(ctx, a, g, stream); break;
         case PAIR_ZP_F64: e = launch_kind<K_ZP, 4>(ctx, a, g, stream); break;      // fallback kind: 64 x 64 only
         case PAIR_KL:
@@ -795,7 +1319,6 @@ int launch_square(hsd_ctx *ctx, const PairArgs &base, int64_t ra, int64_t re) {
     PairArgs b = base;
     b.i_begin = ra; b.i_end = re; b.j_begin = ra; b.j_end = re;
     b.sym = 1; b.mirror = 1; b.swap = 0;
-    if (const char *e = getenv("HSD_NOSYM")) if (atoi(e) != 0 && ctx->mode != PAIR_KL) { b.sym = 0; b.mirror = 0; }   // measurement hook
     return launch_region(ctx, b, tile_edge(ctx), ctx->stream);
 }
 
@@ -918,6 +1441,270 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const int *__restrict_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+namespace {
+
+// device temporary of hsd_pair_prepare: released on every exit path
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    void *release() { void *q = p; p = nullptr; return q; }
+};
+
+#define HSD_TMP_ALLOC(ctx, tmp, bytes) HSD_HIP(ctx, (tmp).alloc(bytes))
+
+int prepare_w1_raw(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int nl_hist) {
+    // scipy on the raw samples: fp64 columns G = CDF x bin width, one block of B - 1 columns per layer >= 1
+    const int cpl = p.B - 1;
+    constexpr int CH = chunk_cols(K_L1);
+    ctx->dcols_alg = nl_hist * cpl;
+    ctx->dcols = (int)round_up(std::max(ctx->dcols_alg, 0), CH);
+    ctx->elem_bytes = 8;
+    const size_t cnt = (size_t)std::max(ctx->dcols, CH) * p.npad;
+    HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(prep_l1_kernel, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, 0, cpl, ctx->d_H);
+    ctx->mode = PAIR_L1_F64;
+    ctx->n_seg = 0;
+    return HSD_OK;
+}
+
+int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int nl_hist) {
+    const int64_t n = p.n, npad = p.npad;
+    const int B = p.B;
+    int rc;
+    // the exact integer path needs integral supports and sums that fit uint32:
+    //   sum_c |U_i - U_j| <= (sum of member values of ring_k(i)) + (same for j) <= 2 * sum_v value(v)
+    bool use_u32 = ctx->support_integral;
+    if (use_u32) {
+        std::vector<int32_t> nb((size_t)n);
+        HSD_HIP(ctx, hipMemcpy(nb.data(), ctx->d_node_bin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        long double tot = 0.0L;
+        for (int64_t i = 0; i < n; ++i) tot += ctx->support[(size_t)nb[(size_t)i]];
+        if (2.0L * tot >= 4294967295.0L) use_u32 = false;
+    }
+    const int CH = use_u32 ? chunk_cols(K_SAD) : chunk_cols(K_ZP);
+    const int stride = (int)round_up(B, CH);                 // unpacked bin columns per segment
+    const int nsg = std::max(nl_hist, 1);
+    ctx->n_seg = nl_hist;
+    ctx->elem_bytes = use_u32 ? 4 : 8;
+    for (int s = 0; s <= nl_hist; ++s) ctx->seg_begin[s] = s * stride;
+
+    // ---- bin form, unpacked: [ n*s0, T(0)*d(0), ..., T(B-2)*d(B-2) ] per layer, + 1/n and n per node ----
+    DevTmp x0, ntot, dseg;
+    const size_t cnt0 = (size_t)std::max(nl_hist * stride, CH) * npad;
+    HSD_TMP_ALLOC(ctx, x0, cnt0 * ctx->elem_bytes);
+    HSD_TMP_ALLOC(ctx, ntot, (size_t)nsg * npad * sizeof(uint32_t));
+    HSD_TMP_ALLOC(ctx, dseg, sizeof(ctx->seg_begin));
+    HSD_HIP(ctx, hipMemsetAsync(x0.p, 0, cnt0 * ctx->elem_bytes, ctx->stream));
+    HSD_HIP(ctx, hipMemsetAsync(ntot.p, 0, (size_t)nsg * npad * sizeof(uint32_t), ctx->stream));
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_inv, (size_t)nsg * npad))) return rc;
+    {   // padded nodes: inv = 2 (treated as empty rings; never stored)
+        std::vector<double> two((size_t)nsg * npad, 2.0);
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_inv, two.data(), two.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HSD_HIP(ctx, hipMemcpyAsync(dseg.p, ctx->seg_begin, sizeof(ctx->seg_begin), hipMemcpyHostToDevice, ctx->stream));
+        if (use_u32)
+            hipLaunchKernelGGL(prep_zp_kernel<uint32_t>, grid, block, 0, ctx->stream, p, x0.as<uint32_t>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(prep_zp_kernel<double>, grid, block, 0, ctx->stream, p, x0.as<double>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `two` leaves scope
+    }
+    HsdSegDesc *tab = ctx->seg_tab;
+    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0};
+    ctx->dcols_alg = nl_hist * B;
+
+    if (!use_u32 || nl_hist == 0) {
+        // fp64 fallback (non-integral support or sums beyond 32 bits): bin form only
+        ctx->d_X = x0.release();
+        ctx->dcols = std::max(nl_hist * stride, CH);
+        ctx->mode = use_u32 ? PAIR_SAD_U32 : PAIR_ZP_F64;
+    } else {
+        // ---- per-column maxima (packing decisions) and per-granule ring maxima (rank form) ----
+        const int ncol32 = nl_hist * stride;
+        const int ngran = (int)(npad / 64);
+        DevTmp cmaxd;
+        HSD_TMP_ALLOC(ctx, cmaxd, (size_t)ncol32 * sizeof(uint32_t));
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax, (size_t)nl_hist * ngran))) return rc;
+        ctx->ngran = ngran;
+        hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)ncol32), dim3(256), 0, ctx->stream, x0.as<uint32_t>(), npad, cmaxd.as<uint32_t>());
+        hipLaunchKernelGGL(granule_max_kernel, dim3((unsigned)ngran, (unsigned)nl_hist), dim3(64), 0, ctx->stream, ntot.as<uint32_t>(), npad, ngran, ctx->d_rmax);
+        std::vector<uint32_t> cmax((size_t)ncol32), rmax((size_t)nl_hist * ngran);
+        HSD_HIP(ctx, hipMemcpyAsync(cmax.data(), cmaxd.p, cmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipMemcpyAsync(rmax.data(), ctx->d_rmax, rmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+        // uint16 packing: two columns per word, one v_sad_u16 covers both.  A column whose values (tail count x bin
+        // width) reach 65536 is split into columns of smaller width (|T_i - T_j| (d1 + d2) is the sum of both parts).
+        const char *e16 = getenv("HSD_SAD16");
+        bool pack = !(e16 && atoi(e16) == 0);
+        std::vector<int> vsrc;
+        std::vector<uint32_t> vdiv, vmul;
+        for (int r = 0; r < B && pack; ++r) {
+            uint32_t mx = 0;                                   // worst layer decides the split of column r
+            for (int sgi = 0; sgi < nl_hist; ++sgi) mx = std::max(mx, cmax[(size_t)sgi * stride + r]);
+            const double width = r == 0 ? ctx->support[0] : ctx->support[(size_t)r] - ctx->support[(size_t)r - 1];
+            const uint32_t wd = (uint32_t)width;
+            if (mx < 65536u) { vsrc.push_back(r); vdiv.push_back(1u); vmul.push_back(1u); continue; }
+            if (wd == 0) { pack = false; break; }
+            const uint32_t tmax = mx / wd;                      // largest count in this column
+            if (tmax > 65535u) { pack = false; break; }
+            const uint32_t dmax = 65535u / tmax;                // widest part that keeps count * part < 65536
+            for (uint32_t left = wd; left > 0;) {
+                const uint32_t d = std::min(left, dmax);
+                vsrc.push_back(r); vdiv.push_back(wd); vmul.push_back(d);
+                left -= d;
+            }
+        }
+        const int V = (int)vsrc.size();
+        if (pack && V > 4 * B) pack = false;
+        const int bin_words = pack ? (V + 1) / 2 : B;
+        const int bin_stride = (int)round_up(bin_words, CH);
+
+        // rank form per layer: worth storing when some 64-node granule's largest ring needs fewer words than the bin form
+        const char *er = getenv("HSD_RANK");
+        bool rank_ok = !(er && atoi(er) == 0);
+        if (pack && ctx->support.back() >= 65536.0) rank_ok = false;      // member values must fit a uint16 half
+        int col = nl_hist * bin_stride;
+        int list_cap = 1;
+        for (int sgi = 0; sgi < nl_hist; ++sgi) {
+            tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0};
+            list_cap += (bin_words + 7) / 8 + 1;        // either kernel: chunks of 32 / 16 words (uint32) or 16 / 8 columns (fp64)
+            if (!rank_ok || bin_words < 2) continue;
+            uint32_t rmin = 0xffffffffu, rall = 0;
+            for (int64_t g = 0; g < (n + 63) / 64; ++g) {
+                rmin = std::min(rmin, rmax[(size_t)sgi * ngran + g]);
+                rall = std::max(rall, rmax[(size_t)sgi * ngran + g]);
+            }
+            const auto words_of = [&](uint32_t R) { return pack ? (int64_t)((R + 1) / 2) : (int64_t)R; };
+            if (words_of(rmin) >= bin_words) continue;           // no tile pair would ever choose it
+            const int cap = (int)std::min<int64_t>(bin_words - 1, words_of(rall));
+            tab[sgi].rank_col0 = col;
+            tab[sgi].rank_cap = cap;
+            col += (int)round_up(cap, CH);
+        }
+        ctx->list_cap = list_cap;
+        ctx->dcols = std::max(col, CH);
+        ctx->dcols_alg = nl_hist * bin_words;
+
+        const size_t cntf = (size_t)ctx->dcols * npad;
+        HSD_HIP(ctx, hipMalloc(&ctx->d_X, cntf * sizeof(uint32_t)));
+        HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cntf * sizeof(uint32_t), ctx->stream));
+        if (pack) {
+            DevTmp dv;
+            HSD_TMP_ALLOC(ctx, dv, (size_t)V * 3 * sizeof(uint32_t));
+            uint32_t *d_vsrc = dv.as<uint32_t>(), *d_vdiv = d_vsrc + V, *d_vmul = d_vdiv + V;
+            HSD_HIP(ctx, hipMemcpyAsync(d_vsrc, vsrc.data(), (size_t)V * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HSD_HIP(ctx, hipMemcpyAsync(d_vdiv, vdiv.data(), (size_t)V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HSD_HIP(ctx, hipMemcpyAsync(d_vmul, vmul.data(), (size_t)V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(pack_u16_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)nl_hist), dim3(256), 0, ctx->stream,
+                               x0.as<uint32_t>(), npad, nl_hist, stride, V, reinterpret_cast<const int *>(d_vsrc), d_vdiv, d_vmul, bin_stride,
+                               (uint32_t *)ctx->d_X);
+            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dv leaves scope
+            ctx->seg_valid16 = bin_words;
+            ctx->mode = PAIR_SAD_U16;
+        } else {
+            for (int sgi = 0; sgi < nl_hist; ++sgi)
+                HSD_HIP(ctx, hipMemcpyAsync((uint32_t *)ctx->d_X + (size_t)sgi * bin_stride * npad, x0.as<uint32_t>() + (size_t)sgi * stride * npad,
+                                            (size_t)B * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->mode = PAIR_SAD_U32;
+        }
+        for (int s = 0; s <= nl_hist; ++s) ctx->seg_begin[s] = s * bin_stride;
+        bool any_rank = false;
+        for (int sgi = 0; sgi < nl_hist; ++sgi) any_rank |= tab[sgi].rank_col0 >= 0;
+        if (any_rank) {
+            DevTmp dr;
+            std::vector<int> rc0((size_t)nl_hist), rcap((size_t)nl_hist);
+            for (int sgi = 0; sgi < nl_hist; ++sgi) { rc0[(size_t)sgi] = tab[sgi].rank_col0; rcap[(size_t)sgi] = tab[sgi].rank_cap; }
+            HSD_TMP_ALLOC(ctx, dr, (size_t)2 * nl_hist * sizeof(int));
+            HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), (size_t)nl_hist * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HSD_HIP(ctx, hipMemcpyAsync(dr.as<int>() + nl_hist, rcap.data(), (size_t)nl_hist * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)nl_hist);
+            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, (uint32_t *)ctx->d_X);
+            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, (uint32_t *)ctx->d_X);
+            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
+        }
+    }
+    if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {
+        ctx->list_cap = 1;
+        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + 7) / 8 + 1;
+    }
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
+    HSD_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tab, tab, (size_t)nsg * sizeof(HsdSegDesc), hipMemcpyHostToDevice, ctx->stream));
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));              // x0 / ntot / dseg leave scope
+    return HSD_OK;
+}
+
+int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metric, double kl_alpha, int kl_sorted) {
+    const int64_t n = p.n, npad = p.npad;
+    const int B = p.B, L = p.L;
+    const int sym = metric == HSD_METRIC_SYMMETRIC_KL;
+    constexpr int CH = chunk_cols(K_DOT);
+    const int half = (int)round_up((int64_t)nl * B, CH);
+    ctx->dcols = sym ? 2 * half : half;
+    ctx->dcols_alg = (sym ? 2 : 1) * nl * B;
+    ctx->elem_bytes = 8;
+    const size_t cnt = (size_t)ctx->dcols * npad;
+    HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
+    HSD_HIP(ctx, hipMalloc(&ctx->d_Y, cnt * sizeof(double)));
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_Y, 0, cnt * sizeof(double), ctx->stream));
+    DevTmp hpart, sorted;
+    HSD_TMP_ALLOC(ctx, hpart, (size_t)nl * npad * sizeof(double));
+    if (kl_sorted) {
+        int Bp2 = 1;
+        while (Bp2 < B) Bp2 <<= 1;
+        HSD_TMP_ALLOC(ctx, sorted, (size_t)n * L * B * sizeof(uint32_t));
+        hipLaunchKernelGGL(sort_counts_kernel, dim3((unsigned)(n * L)), dim3(std::min(256, std::max(64, Bp2 / 2))),
+                           (size_t)Bp2 * sizeof(uint32_t), ctx->stream, ctx->d_counts, sorted.as<uint32_t>(), B, Bp2);
+        p.counts = sorted.as<uint32_t>();
+    }
+    hipLaunchKernelGGL(prep_kl_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
+                       (double *)ctx->d_Y, hpart.as<double>());
+    hipLaunchKernelGGL(sum_layers_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, hpart.as<double>(), nl, npad, n, ctx->d_H);
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));              // temporaries leave scope
+    ctx->mode = sym ? PAIR_SKL : PAIR_KL;
+    ctx->n_seg = 0;
+    return HSD_OK;
+}
+
+int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int layer_hi, double kl_alpha, int kl_sorted) {
+    const int64_t n = ctx->n;
+    const int L = ctx->hop + 1, B = ctx->n_bins;
+    const int64_t npad = round_up(n + HSD_TILE, HSD_TILE);
+    ctx->npad = npad;
+    ctx->list_cap = 0;
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
+    PrepArgs p{ctx->d_counts, ctx->d_support, ctx->d_node_bin, n, npad, L, B, layer_lo, layer_hi, ctx->d_flag};
+    const int nl = layer_hi - layer_lo + 1;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nl), block(256);
+    int rc;
+    // d_H: per-node entropy term (KL) or the ring-0 point values (W1 with layer 0)
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)npad))) return rc;
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)npad * sizeof(double), ctx->stream));
+    if (metric == HSD_METRIC_WASSERSTEIN) {
+        const int nl_hist = nl - (layer_lo == 0 ? 1 : 0);
+        rc = align == HSD_ALIGN_NONE ? prepare_w1_raw(ctx, p, grid, block, nl_hist) : prepare_w1_zeropad(ctx, p, grid, block, nl_hist);
+        ctx->d_Y = nullptr;
+    } else {
+        rc = prepare_kl(ctx, p, grid, block, nl, metric, kl_alpha, kl_sorted);
+    }
+    if (rc) return rc;
+    int flag[4] = {0, 0, 0, 0};
+    HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    HSD_HIP(ctx, hipGetLastError());
+    // ring-0 point values in use? (d_H doubles as the point array for W1)
+    ctx->has_point = metric == HSD_METRIC_WASSERSTEIN && layer_lo == 0;
+    if (metric == HSD_METRIC_WASSERSTEIN && align == HSD_ALIGN_NONE && (flag[0] & 1))
+        return hsd_fail(ctx, HSD_ERR_EMPTY_RING, "Distribution can't be empty.");
+    if (metric != HSD_METRIC_WASSERSTEIN && (flag[0] & 2))
+        return hsd_fail(ctx, HSD_ERR_NOT_NORMALISED, "The sum of probability distribution must be 1.0.");
+    return HSD_OK;
+}
+
+}  // namespace
+
 extern "C" int hsd_pair_prepare(hsd_ctx *ctx, int metric, int align, int layer_lo, int layer_hi, double kl_alpha,
                                 int kl_sorted) {
     HSD_CHECK_CTX(ctx);
@@ -930,256 +1717,31 @@ extern "C" int hsd_pair_prepare(hsd_ctx *ctx, int metric, int align, int layer_l
     if (!(kl_alpha >= 0.0)) return hsd_fail(ctx, HSD_ERR_INVALID, "kl_alpha must be >= 0");
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hsd_release_operands(ctx);
-
-    const int64_t n = ctx->n;
-    const int L = ctx->hop + 1, B = ctx->n_bins;
-    const int64_t npad = round_up(n + HSD_TILE, HSD_TILE);
-    ctx->npad = npad;
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
-    PrepArgs p{ctx->d_counts, ctx->d_support, ctx->d_node_bin, n, npad, L, B, layer_lo, layer_hi, ctx->d_flag};
-    const int nl = layer_hi - layer_lo + 1;
-    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nl), block(256);
-    int rc;
-    double *d_point = nullptr;
-    uint32_t *d_sorted = nullptr;
-
-    if (metric == HSD_METRIC_WASSERSTEIN) {
-        const bool has_point = layer_lo == 0;
-        const int nl_hist = nl - (has_point ? 1 : 0);
-        // ring-0 values live at the tail of d_H (reused as the `point` array)
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)npad))) return rc;
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)npad * sizeof(double), ctx->stream));
-        d_point = ctx->d_H;
-        if (align == HSD_ALIGN_NONE) {
-            const int cpl = B - 1;
-            // exact-integer form when every product and every layer sum fits uint32:
-            //   (largest ring) x (largest cumulative count x bin width) x (bins) < 2^32, operands < 2^24
-            // Opt-in (HSD_RAT=1): measured SLOWER than the fp64 kernel on MI355X (0.43 vs 0.33 ms at
-            // ER N=10k) -- two v_mul_u32_u24 plus a v_sad_u32 per column pair cost as many issue
-            // cycles as two v_add_f64 (the 3-operand SAD runs at the fp64 rate) and form a dependent
-            // chain.  Kept because it is exact to the last bit of the final division.
-            const char *erat = getenv("HSD_RAT");
-            bool use_rat = erat && atoi(erat) != 0 && ctx->support_integral && nl_hist > 0 && cpl > 0;
-            if (use_rat) {
-                constexpr int CHR = chunk_cols(K_RAT);
-                const int stride = (int)round_up(cpl, CHR);
-                const size_t cnt = (size_t)nl_hist * stride * npad;
-                uint32_t *d_Xr = nullptr, *d_cmax = nullptr;
-                HSD_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_Xr), cnt * sizeof(uint32_t)));
-                HSD_HIP(ctx, hipMemsetAsync(d_Xr, 0, cnt * sizeof(uint32_t), ctx->stream));
-                if ((rc = hsd_dev_alloc(ctx, &ctx->d_nring, (size_t)nl_hist * npad)) || (rc = hsd_dev_alloc(ctx, &ctx->d_inv, (size_t)nl_hist * npad)) ||
-                    (rc = hsd_dev_alloc(ctx, &d_cmax, (size_t)nl_hist * stride + nl_hist))) {
-                    (void)hipFree(d_Xr);
-                    return rc;
-                }
-                HSD_HIP(ctx, hipMemsetAsync(ctx->d_nring, 0, (size_t)nl_hist * npad * sizeof(uint32_t), ctx->stream));
-                HSD_HIP(ctx, hipMemsetAsync(ctx->d_inv, 0, (size_t)nl_hist * npad * sizeof(double), ctx->stream));
-                hipLaunchKernelGGL(prep_rat_kernel, grid, block, 0, ctx->stream, p, d_Xr, ctx->d_nring, ctx->d_inv, d_point, stride);
-                hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)(nl_hist * stride)), dim3(256), 0, ctx->stream, d_Xr, npad, d_cmax);
-                hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)nl_hist), dim3(256), 0, ctx->stream, ctx->d_nring, npad,
-                                   d_cmax + (size_t)nl_hist * stride);
-                std::vector<uint32_t> cmax((size_t)nl_hist * stride + nl_hist);
-                HSD_HIP(ctx, hipMemcpyAsync(cmax.data(), d_cmax, cmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                hsd_dev_free(d_cmax);
-                for (int sgi = 0; sgi < nl_hist && use_rat; ++sgi) {
-                    uint64_t mc = 0;
-                    for (int b = 0; b < cpl; ++b) mc = std::max<uint64_t>(mc, cmax[(size_t)sgi * stride + b]);
-                    const uint64_t mn = cmax[(size_t)nl_hist * stride + sgi];
-                    if (mc >= (1u << 24) || mn >= (1u << 24) || mc * mn * (uint64_t)cpl >= 0xffffffffull) use_rat = false;
-                }
-                if (use_rat) {
-                    ctx->d_X = d_Xr;
-                    ctx->n_seg = nl_hist;
-                    for (int sgi = 0; sgi <= nl_hist; ++sgi) ctx->seg_begin[sgi] = sgi * stride;
-                    ctx->dcols = nl_hist * stride;
-                    ctx->dcols_alg = nl_hist * cpl;
-                    ctx->elem_bytes = 4;
-                    ctx->mode = PAIR_RAT_U32;
-                } else {
-                    (void)hipFree(d_Xr);
-                    hsd_dev_free(ctx->d_nring);
-                    hsd_dev_free(ctx->d_inv);
-                }
-            }
-            if (!use_rat) {
-                ctx->dcols_alg = nl_hist * cpl;
-                constexpr int CH = chunk_cols(K_L1);
-                ctx->dcols = (int)round_up(std::max(ctx->dcols_alg, 0), CH);
-                ctx->elem_bytes = 8;
-                const size_t cnt = (size_t)std::max(ctx->dcols, CH) * npad;
-                HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
-                HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
-                hipLaunchKernelGGL(prep_l1_kernel, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, 0, cpl, d_point);
-                ctx->mode = PAIR_L1_F64;
-                ctx->n_seg = 0;
-            }
-        } else {
-            // exact integer path needs integral supports and sums that fit uint32
-            bool use_u32 = ctx->support_integral;
-            if (use_u32) {
-                // sum_c |U_i - U_j| <= (sum of member values of ring_k(i)) + (same for j) <= 2 * sum_v value(v)
-                std::vector<int32_t> nb((size_t)n);
-                HSD_HIP(ctx, hipMemcpy(nb.data(), ctx->d_node_bin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-                long double tot = 0.0L;
-                for (int64_t i = 0; i < n; ++i) tot += ctx->support[(size_t)nb[(size_t)i]];
-                if (2.0L * tot >= 4294967295.0L) use_u32 = false;
-            }
-            const int CH = use_u32 ? chunk_cols(K_SAD) : chunk_cols(K_ZP);
-            ctx->n_seg = nl_hist;
-            int col = 0;
-            for (int s = 0; s < nl_hist; ++s) {
-                ctx->seg_begin[s] = col;
-                col += (int)round_up(B, CH);
-            }
-            ctx->seg_begin[nl_hist] = col;
-            ctx->dcols = col;
-            ctx->dcols_alg = nl_hist * B;
-            ctx->elem_bytes = use_u32 ? 4 : 8;
-            const size_t cnt = (size_t)std::max(col, CH) * npad;
-            HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * ctx->elem_bytes));
-            HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * ctx->elem_bytes, ctx->stream));
-            if ((rc = hsd_dev_alloc(ctx, &ctx->d_inv, (size_t)std::max(nl_hist, 1) * npad))) return rc;
-            // padded nodes: inv = 2 (treated as empty rings; never stored)
-            std::vector<double> two((size_t)std::max(nl_hist, 1) * npad, 2.0);
-            HSD_HIP(ctx, hipMemcpyAsync(ctx->d_inv, two.data(), two.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-            int *d_seg = nullptr;
-            if ((rc = hsd_dev_alloc(ctx, &d_seg, HSD_MAX_LAYERS + 1))) return rc;
-            HSD_HIP(ctx, hipMemcpyAsync(d_seg, ctx->seg_begin, sizeof(ctx->seg_begin), hipMemcpyHostToDevice, ctx->stream));
-            if (use_u32)
-                hipLaunchKernelGGL(prep_zp_kernel<uint32_t>, grid, block, 0, ctx->stream, p, (uint32_t *)ctx->d_X, ctx->d_inv, d_point, d_seg);
-            else
-                hipLaunchKernelGGL(prep_zp_kernel<double>, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, ctx->d_inv, d_point, d_seg);
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            hsd_dev_free(d_seg);
-            ctx->mode = use_u32 ? PAIR_SAD_U32 : PAIR_ZP_F64;
-            const char *e16 = getenv("HSD_SAD16");
-            if (use_u32 && nl_hist > 0 && !(e16 && atoi(e16) == 0)) {
-                // uint16 packing: two columns per word, one v_sad_u16 covers both.  A column whose
-                // values (tail count x bin width) reach 65536 is split into columns of smaller width.
-                const int stride32 = ctx->seg_begin[1] - ctx->seg_begin[0];
-                const int ncol32 = nl_hist * stride32;
-                uint32_t *d_cmax = nullptr;
-                if ((rc = hsd_dev_alloc(ctx, &d_cmax, (size_t)ncol32))) return rc;
-                hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)ncol32), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, d_cmax);
-                std::vector<uint32_t> cmax((size_t)ncol32);
-                HSD_HIP(ctx, hipMemcpyAsync(cmax.data(), d_cmax, cmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                hsd_dev_free(d_cmax);
-                std::vector<int> vsrc;
-                std::vector<uint32_t> vdiv, vmul;
-                bool ok = true;
-                for (int r = 0; r < B && ok; ++r) {
-                    uint32_t mx = 0;                                   // worst layer decides the split of column r
-                    for (int sgi = 0; sgi < nl_hist; ++sgi) mx = std::max(mx, cmax[(size_t)sgi * stride32 + r]);
-                    const double width = r == 0 ? ctx->support[0] : ctx->support[(size_t)r] - ctx->support[(size_t)r - 1];
-                    const uint32_t wd = (uint32_t)width;
-                    if (mx < 65536u || wd == 0) {
-                        vsrc.push_back(r); vdiv.push_back(1u); vmul.push_back(1u);
-                        if (mx >= 65536u) ok = false;
-                        continue;
-                    }
-                    const uint32_t tmax = mx / wd;                      // largest count in this column
-                    if (tmax > 65535u) { ok = false; break; }
-                    const uint32_t dmax = 65535u / tmax;                // widest part that keeps count * part < 65536
-                    for (uint32_t left = wd; left > 0;) {
-                        const uint32_t d = std::min(left, dmax);
-                        vsrc.push_back(r); vdiv.push_back(wd); vmul.push_back(d);
-                        left -= d;
-                    }
-                }
-                const int V = (int)vsrc.size();
-                if (ok && V <= 4 * B) {
-                    const int CH16 = chunk_cols(K_SAD16);
-                    const int valid16 = (V + 1) / 2;
-                    const int stride16 = (int)round_up(valid16, CH16);
-                    const size_t cnt16 = (size_t)std::max(nl_hist * stride16, CH16) * npad;
-                    void *d_X16 = nullptr;
-                    int *d_vsrc = nullptr;
-                    uint32_t *d_vdiv = nullptr, *d_vmul = nullptr;
-                    HSD_HIP(ctx, hipMalloc(&d_X16, cnt16 * sizeof(uint32_t)));
-                    if ((rc = hsd_dev_alloc(ctx, &d_vsrc, (size_t)V)) || (rc = hsd_dev_alloc(ctx, &d_vdiv, (size_t)V)) ||
-                        (rc = hsd_dev_alloc(ctx, &d_vmul, (size_t)V))) {
-                        (void)hipFree(d_X16); hsd_dev_free(d_vsrc); hsd_dev_free(d_vdiv); hsd_dev_free(d_vmul);
-                        return rc;
-                    }
-                    HSD_HIP(ctx, hipMemsetAsync(d_X16, 0, cnt16 * sizeof(uint32_t), ctx->stream));
-                    HSD_HIP(ctx, hipMemcpyAsync(d_vsrc, vsrc.data(), (size_t)V * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-                    HSD_HIP(ctx, hipMemcpyAsync(d_vdiv, vdiv.data(), (size_t)V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                    HSD_HIP(ctx, hipMemcpyAsync(d_vmul, vmul.data(), (size_t)V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                    hipLaunchKernelGGL(pack_u16_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)nl_hist), dim3(256), 0, ctx->stream,
-                                       (const uint32_t *)ctx->d_X, npad, nl_hist, stride32, V, d_vsrc, d_vdiv, d_vmul, stride16,
-                                       (uint32_t *)d_X16);
-                    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    hsd_dev_free(d_vsrc); hsd_dev_free(d_vdiv); hsd_dev_free(d_vmul);
-                    (void)hipFree(ctx->d_X);
-                    ctx->d_X = d_X16;
-                    for (int sgi = 0; sgi <= nl_hist; ++sgi) ctx->seg_begin[sgi] = sgi * stride16;
-                    ctx->dcols = nl_hist * stride16;
-                    ctx->dcols_alg = nl_hist * valid16;
-                    ctx->seg_valid16 = valid16;
-                    ctx->mode = PAIR_SAD_U16;
-                }
-            }
-        }
-        if (!has_point) d_point = nullptr;
-        ctx->d_Y = nullptr;
-    } else {
-        const int sym = metric == HSD_METRIC_SYMMETRIC_KL;
-        constexpr int CH = chunk_cols(K_DOT);
-        const int half = (int)round_up((int64_t)nl * B, CH);
-        ctx->dcols = sym ? 2 * half : half;
-        ctx->dcols_alg = (sym ? 2 : 1) * nl * B;
-        ctx->elem_bytes = 8;
-        const size_t cnt = (size_t)ctx->dcols * npad;
-        HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
-        HSD_HIP(ctx, hipMalloc(&ctx->d_Y, cnt * sizeof(double)));
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_Y, 0, cnt * sizeof(double), ctx->stream));
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)npad))) return rc;
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)npad * sizeof(double), ctx->stream));
-        double *d_hpart = nullptr;
-        if ((rc = hsd_dev_alloc(ctx, &d_hpart, (size_t)nl * npad))) return rc;
-        if (kl_sorted) {
-            int Bp2 = 1;
-            while (Bp2 < B) Bp2 <<= 1;
-            if ((rc = hsd_dev_alloc(ctx, &d_sorted, (size_t)n * L * B))) return rc;
-            hipLaunchKernelGGL(sort_counts_kernel, dim3((unsigned)(n * L)), dim3(std::min(256, std::max(64, Bp2 / 2))),
-                               (size_t)Bp2 * sizeof(uint32_t), ctx->stream, ctx->d_counts, d_sorted, B, Bp2);
-            p.counts = d_sorted;
-        }
-        hipLaunchKernelGGL(prep_kl_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
-                           (double *)ctx->d_Y, d_hpart);
-        hipLaunchKernelGGL(sum_layers_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, d_hpart, nl, npad, n, ctx->d_H);
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        hsd_dev_free(d_hpart);
-        hsd_dev_free(d_sorted);
-        ctx->mode = sym ? PAIR_SKL : PAIR_KL;
-        ctx->n_seg = 0;
-    }
-    int flag[4] = {0, 0, 0, 0};
-    HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    HSD_HIP(ctx, hipGetLastError());
-    // ring-0 point values in use? (d_H doubles as the point array for W1)
-    ctx->has_point = metric == HSD_METRIC_WASSERSTEIN && layer_lo == 0;
-    if (metric == HSD_METRIC_WASSERSTEIN && align == HSD_ALIGN_NONE && (flag[0] & 1)) {
+    // a failure on any path leaves no half-built operands behind (mode stays PAIR_NONE)
+    const int rc = pair_prepare_impl(ctx, metric, align, layer_lo, layer_hi, kl_alpha, kl_sorted);
+    if (rc != HSD_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
         hsd_release_operands(ctx);
-        return hsd_fail(ctx, HSD_ERR_EMPTY_RING, "Distribution can't be empty.");
     }
-    if (metric != HSD_METRIC_WASSERSTEIN && (flag[0] & 2)) {
-        hsd_release_operands(ctx);
-        return hsd_fail(ctx, HSD_ERR_NOT_NORMALISED, "The sum of probability distribution must be 1.0.");
-    }
-    return HSD_OK;
+    return rc;
 }
 
 extern "C" int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element) {
     HSD_CHECK_CTX(ctx);
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64 || ctx->mode == PAIR_RAT_U32;
+    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
     if (n_columns) *n_columns = ctx->dcols_alg + ((wass && ctx->has_point) ? 1 : 0);
     if (bytes_per_element) *bytes_per_element = ctx->elem_bytes;
+    return HSD_OK;
+}
+
+extern "C" int hsd_pair_work(hsd_ctx *ctx, double *column_pairs) {
+    HSD_CHECK_CTX(ctx);
+    if (!column_pairs) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
+    unsigned long long w = 0;
+    HSD_HIP(ctx, hipMemcpyAsync(&w, ctx->d_work, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *column_pairs = (double)w;
     return HSD_OK;
 }
 
@@ -1190,23 +1752,26 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
     if (r0 < 0 || r1 > n || r0 > r1) return hsd_fail(ctx, HSD_ERR_INVALID, "row range out of bounds");
     if (r0 == r1) return HSD_OK;
     if (!out || ld < n) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_pair_rows: null out or ld < n");
-    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64 || ctx->mode == PAIR_RAT_U32;
+    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
 
     PairArgs a{};
     a.X = ctx->d_X;
     a.Y = wass ? ctx->d_X : ctx->d_Y;
     a.H = wass ? nullptr : ctx->d_H;
     a.inv = ctx->d_inv;
-    a.nring = ctx->d_nring;
     a.point = (wass && ctx->has_point) ? ctx->d_H : nullptr;
     a.npad = ctx->npad;
     a.dcols = ctx->dcols;
     a.n_seg = ctx->n_seg;
-    a.seg_stride = ctx->n_seg > 0 ? ctx->seg_begin[1] - ctx->seg_begin[0] : 0;
+    a.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
+    a.rmax = ctx->d_rmax;
+    a.ngran = ctx->ngran;
+    a.list_cap = ctx->list_cap;
+    a.work = ctx->d_work;
     a.hmode = ctx->mode == PAIR_SKL ? 1 : 0;
     { const char *e = getenv("HSD_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     a.dcols_valid = (ctx->mode == PAIR_SKL) ? ctx->dcols : ctx->dcols_alg;
-    a.seg_valid = ctx->mode == PAIR_SAD_U16 ? ctx->seg_valid16 : (ctx->mode == PAIR_RAT_U32 ? ctx->n_bins - 1 : ctx->n_bins);
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned long long), ctx->stream));
 
     auto run = [&](double *dout, int64_t dld, int64_t rb, int64_t ra, int64_t re) -> int {
         // rows [ra, re) of the matrix; dout row 0 <-> node rb
@@ -1292,22 +1857,24 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     if (r0 == r1) return HSD_OK;
     if (!idx_out || !dist_out) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
     const int64_t rows = r1 - r0;
-    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64 || ctx->mode == PAIR_RAT_U32;
+    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
 
     PairArgs a{};
     a.X = ctx->d_X;
     a.Y = wass ? ctx->d_X : ctx->d_Y;
     a.H = wass ? nullptr : ctx->d_H;
     a.inv = ctx->d_inv;
-    a.nring = ctx->d_nring;
     a.point = (wass && ctx->has_point) ? ctx->d_H : nullptr;
     a.npad = ctx->npad;
     a.dcols = ctx->dcols;
     a.n_seg = ctx->n_seg;
-    a.seg_stride = ctx->n_seg > 0 ? ctx->seg_begin[1] - ctx->seg_begin[0] : 0;
+    a.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
+    a.rmax = ctx->d_rmax;
+    a.ngran = ctx->ngran;
+    a.list_cap = ctx->list_cap;
+    a.work = nullptr;
     a.hmode = ctx->mode == PAIR_SKL ? 1 : 0;
     a.dcols_valid = (ctx->mode == PAIR_SKL) ? ctx->dcols : ctx->dcols_alg;
-    a.seg_valid = ctx->mode == PAIR_SAD_U16 ? ctx->seg_valid16 : (ctx->mode == PAIR_RAT_U32 ? ctx->n_bins - 1 : ctx->n_bins);
     a.rbase = r0;
     a.i_begin = r0; a.i_end = r1;
 

@@ -254,6 +254,12 @@ class Engine:
         self._call("hsd_pair_operand_dims", C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def pair_work(self):
+        """operand columns x pairs evaluated by the last pair_rows call (synchronises)."""
+        out = C.c_double()
+        self._call("hsd_pair_work", C.byref(out))
+        return out.value
+
     def pair_rows_host(self, r0=0, r1=None):
         r1 = self.n if r1 is None else r1
         out = np.empty((r1 - r0, self.n), dtype=np.float64)

@@ -156,6 +156,10 @@ int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, int64_t ld,
 int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out);
 /* algorithmic size of the prepared operands: columns per node and bytes per element */
 int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element);
+/* Work of the last hsd_pair_rows call: operand columns (words) x node pairs the kernel evaluated, counted by the
+ * kernel itself.  Below pairs x hsd_pair_operand_dims' columns when tile pairs took the shorter rank form of a
+ * zero-pad layer (csrc/pair.hip, SegDesc); the measurement harness prices the vector-ALU rate with it. */
+int hsd_pair_work(hsd_ctx *ctx, double *column_pairs);
 
 /* ---- K4 and the reference's own coefficient signatures ----------------------------------
  * psi = exp(-s L) is dense N x N: this path serves graphs whose N^2 fits in HBM; the histogram

@@ -16,6 +16,33 @@ from oracle import c_oracle as _corc  # noqa: E402
 _corc.lib()
 
 
+# The plain-C client of include/hsd.h is compiled here for the same reason (tests/test_gpu_forms.py runs it).
+def _build_c_client():
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="hsd_abi_"), "abi_client")
+    libdir = os.path.join(REPO, "hsd_amd")
+    if not os.path.exists(os.path.join(libdir, "libhsd_amd.so")):
+        return None
+    try:
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                               os.path.join(REPO, "tests", "c", "abi_client.c"), "-o", exe, "-L", libdir, "-lhsd_amd",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return exe
+
+
+_C_CLIENT = _build_c_client()
+
+
+@pytest.fixture(scope="session")
+def c_client():
+    if _C_CLIENT is None:
+        pytest.fail("tests/c/abi_client.c did not build (gcc + hsd_amd/libhsd_amd.so are required)")
+    return _C_CLIENT
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -1,0 +1,157 @@
+"""GPU: alternative evaluation forms of the zero-pad distance give identical results.
+
+* rank form vs bin form of a layer (csrc/pair.hip, SegDesc): the same integer sum, so matrices must be
+  BIT-identical with the rank form disabled (HSD_RANK=0), for packed uint16 and plain uint32 operands, both tile
+  shapes, aligned and unaligned row ranges, and against the oracle;
+* the fp64 fallback kernel (PAIR_ZP_F64) that serves non-integral supports -- reachable through
+  hsd_signature_build with fractional node values -- against the oracle on the raw samples;
+* the plain-C client of include/hsd.h runs the hot path end to end as a separate (non-Python) process.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-6, 1e-12
+
+
+class _Env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update({k: str(v) for k, v in self.kw.items()})
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _scale_free(n, seed=42):
+    from hsd_amd.graph import barabasi_albert
+    return barabasi_albert(n, 5, seed)
+
+
+@pytest.mark.parametrize("n", [1500, 3001])
+@pytest.mark.parametrize("pack", [1, 0])
+def test_rank_form_bit_identical_to_bin_form(engine, n, pack):
+    from oracle import c_oracle as corc
+    g = _scale_free(n)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    mats = {}
+    for rank in (1, 0):
+        for tile in (64, 128):
+            with _Env(HSD_RANK=rank, HSD_SAD16=pack, HSD_TILE=tile):
+                engine.pair_prepare(0, 1, 0, 2)
+                mats[(rank, tile)] = engine.pair_rows_host()
+                if rank == 1 and tile == 128:
+                    work_rank = engine.pair_work()
+                    cols, _ = engine.pair_operand_dims()
+                    # an unaligned row block (register-staged kernel instead of direct-to-LDS loads)
+                    blk = engine.pair_rows_host(n // 2 + 1, n // 2 + 131)
+                    assert np.array_equal(blk, mats[(1, 128)][n // 2 + 1:n // 2 + 131])
+                if rank == 0 and tile == 128:
+                    work_bin = engine.pair_work()
+    ref = mats[(0, 128)]
+    for key, m in mats.items():
+        assert np.array_equal(m, ref), key
+    # the rank form was really taken: ring 1 of a scale-free graph has ~10 members against >100 degree bins
+    assert work_rank < 0.8 * work_bin, (work_rank, work_bin)
+    rs = corc.RingSamples(g.rowptr, g.col, 3, g.degree.astype(np.float64))
+    want, _ = rs.pair_rows(0, 2, corc.ALIGN_ZEROPAD, 0, 48)
+    assert np.allclose(ref[:48], want, rtol=RTOL, atol=ATOL), np.abs(ref[:48] - want).max()
+    assert np.array_equal(ref, ref.T) and not ref.diagonal().any()
+
+
+def test_rank_form_topk_and_hop1(engine):
+    """The fused k-nearest consumer runs the same tile kernel (chunk list included); K = 1 leaves only layer 0
+    (no histogram layer at all: an empty chunk list)."""
+    g = _scale_free(2000)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 1, 0, 2)
+    D = engine.pair_rows_host()
+    idx, dist = engine.pair_topk(7)
+    for i in (0, 5, 1234, 1999):
+        d = D[i].copy()
+        d[i] = np.inf
+        order = np.lexsort((np.arange(len(d)), d))[:7]
+        assert np.array_equal(idx[i], order) and np.array_equal(dist[i], d[order])
+    engine.signature_build_degree(1)
+    engine.pair_prepare(0, 1, 0, 0)
+    D0 = engine.pair_rows_host()
+    deg = g.degree.astype(np.float64)
+    assert np.array_equal(D0, np.abs(deg[:, None] - deg[None, :]))
+
+
+def test_zeropad_fp64_fallback_matches_oracle(engine):
+    """Non-integral support -> the exact integer kernels do not apply; the fp64 zero-pad kernel takes over."""
+    from hsd_amd.graph import erdos_renyi
+    from oracle import c_oracle as corc
+    g = erdos_renyi(900, 0.012, seed=5)
+    value = np.round(np.sqrt(g.degree.astype(np.float64) + 0.25), 3)          # fractional, few distinct values
+    support = np.unique(value)
+    node_bin = np.searchsorted(support, value).astype(np.int32)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build(3, node_bin, support)
+    rs = corc.RingSamples(g.rowptr, g.col, 3, value)
+    for align, lo, hi in ((1, 0, 2), (1, 1, 3)):
+        engine.pair_prepare(0, align, lo, hi)
+        cols, ebytes = engine.pair_operand_dims()
+        assert ebytes == 8                                                    # the fp64 kind, not uint32
+        D = engine.pair_rows_host()
+        want, _ = rs.pair_rows(lo, hi, corc.ALIGN_ZEROPAD, 0, 64)
+        assert np.allclose(D[:64], want, rtol=RTOL, atol=ATOL), np.abs(D[:64] - want).max()
+        assert np.array_equal(D, D.T)
+    # and the raw-sample distance on the same fractional support (no empty rings in the layers compared)
+    sizes = engine.khop_sizes(3)
+    if not (sizes[:, :3] == 0).any():
+        engine.pair_prepare(0, 0, 0, 2)
+        D = engine.pair_rows_host()
+        want, _ = rs.pair_rows(0, 2, corc.ALIGN_NONE, 0, 64)
+        assert np.allclose(D[:64], want, rtol=RTOL, atol=ATOL)
+
+
+def test_plain_c_client_runs_the_hot_path(engine, c_client):
+    """tests/c/abi_client.c gpu: k-hop sizes, signature, prepare, rows and the error contract from a C99 program
+    (built at collection time, before this process touched the GPU; started as a fresh child process)."""
+    out = subprocess.run([c_client, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "abi ok (gpu)" in out.stdout
+
+
+@pytest.mark.parametrize("nw", [4, 1])
+def test_persistent_kernels_bit_identical(engine, nw):
+    """pair_stream_kernel (persistent workgroups streaming through their tiles, 4 waves or 1) against the
+    one-tile-per-workgroup kernel: same per-pair operation order, so every distance kind must agree bit for bit --
+    full matrix (diagonal square, mirrored) and a row block with rectangles left and right of it."""
+    g = _scale_free(3001, seed=7)
+    n = g.n_node
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    cases = [(0, 1, 0, 2), (0, 0, 0, 3), (1, 0, 0, 3), (2, 0, 0, 3), (0, 1, 1, 3)]     # (metric, align, lo, hi)
+    for metric, align, lo, hi in cases:
+        with _Env(HSD_STREAM=0):
+            engine.pair_prepare(metric, align, lo, hi)
+            ref = engine.pair_rows_host()
+            blk_ref = engine.pair_rows_host(1024, 2048)
+        with _Env(HSD_STREAM=nw):
+            engine.pair_prepare(metric, align, lo, hi)
+            got = engine.pair_rows_host()
+            blk = engine.pair_rows_host(1024, 2048)
+            work = engine.pair_work()
+        assert np.array_equal(got, ref), (metric, align, lo, hi, np.abs(got - ref).max())
+        assert np.array_equal(blk, blk_ref)
+        # (a row block evaluates the pairs below the diagonal itself instead of mirroring them: symmetric KL then sums
+        # its two halves in the other order)
+        assert np.array_equal(blk, ref[1024:2048]) if metric != 2 else np.allclose(blk, ref[1024:2048], rtol=1e-9, atol=1e-15)
+        assert work > 0

@@ -241,3 +241,44 @@ def test_config4_ba200k_row_blocks_of_two_ranks(engine):
     finally:
         A.free()
         B.free()
+
+
+def test_config5_multihsd_ba50k_full_size(engine):
+    """BASELINE config 5 at FULL size: MultiHSD heat-kernel signatures, 8 log-spaced scales, BA N = 50 000 m = 5,
+    K = 3, Chebyshev order 50, threshold 1e-4/N (model/multiscale_HSD.py:45-61,76-98).  parallel_embed against the
+    numpy/scipy.sparse restatement of the PyGSP recurrence (oracle.cheby_heat_apply) + get_triple on sampled source
+    nodes -- hubs, mid-age and the youngest node -- all 8 scales."""
+    import hsd_amd
+    from scipy.sparse import csr_matrix
+    from hsd_amd.graph import barabasi_albert
+    from oracle import hsd_oracle as orc
+    g = barabasi_albert(50000, 5, 42)
+    n, K, S = g.n_node, 3, 8
+    m = hsd_amd.MultiHSD(g, "ba50000", K, S, engine=engine)
+    assert len(m.scales) == S and np.isclose(m.scales[0], 0.01) and np.isclose(m.scales[-1], 1.25 * m.lmax)
+    emb = m.parallel_embed(1, approx=True)
+    assert len(emb) == n and all(len(emb[v]) == S * (K + 1) * 2 for v in (0, n - 1))
+    rp, c, v = g.laplacian_csr()
+    L = csr_matrix((v, c, rp), shape=(n, n))
+    nodes = [0, 3, 777, 25000, 41234, n - 1]
+    E = np.zeros((n, len(nodes)))
+    for t, u in enumerate(nodes):
+        E[u, t] = 1.0
+    rings = {u: orc.khop_rings_node(g.rowptr, g.col, u, K) for u in nodes}
+    sizes = engine.khop_sizes(K)
+    for u in nodes:
+        assert [len(r) for r in rings[u]] == list(sizes[u])
+    for si, s in enumerate(m.scales):
+        cc = orc.cheby_coeff_heat(s, m.lmax, 50)
+        R = orc.cheby_heat_apply(L, cc, m.lmax, E)
+        for t, u in enumerate(nodes):
+            row = orc.threshold_wavelets(R[:, t], n)
+            ref = np.asarray(orc.get_triple(row[None, :], rings[u], 0))
+            got = np.asarray(emb[u][si * 2 * (K + 1):(si + 1) * 2 * (K + 1)])
+            # an entry within rounding of the 1e-4/N = 2e-9 threshold may be kept by one side only: each flip moves
+            # a ring sum by at most 2e-9
+            assert np.allclose(got, ref, rtol=1e-6, atol=2e-8), (si, u, got, ref)
+    # ring 0 is the node itself: sum == mean == psi[i, i] in (0, 1]; sums over all rings of one scale are <= 1
+    for u in nodes:
+        e = np.asarray(emb[u]).reshape(S, K + 1, 2)
+        assert np.all(e[:, 0, 0] == e[:, 0, 1]) and np.all(e[:, 0, 0] > 0) and np.all(e[:, :, 0].sum(axis=1) <= 1 + 1e-9)
