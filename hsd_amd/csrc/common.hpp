@@ -77,6 +77,7 @@ struct hsd_ctx {
     uint32_t *d_rmax = nullptr;        // zero-pad rank form: largest ring per layer and 64-node granule [n_seg][ngran]
     int ngran = 0;
     int list_cap = 0;                  // entries of the pair kernel's per-tile chunk list (LDS)
+    int *d_tile_ctr = nullptr;         // persistent pair kernel: 4 sets of 8 per-XCD tile counters
     unsigned long long *d_work = nullptr;   // operand words x pairs evaluated by the last hsd_pair_rows (hsd_pair_work)
     double *d_inv = nullptr;           // zero-pad: 1/ring size per layer [n_seg][npad]
     int n_seg = 0;                     // zero-pad: number of layer segments
@@ -110,7 +111,7 @@ struct hsd_ctx {
     int64_t rows_per_rank = 0;
 
     // cached explicit tile orders of the pair kernel (device int2 arrays)
-    struct TileList { int tiles_i, tiles_j, sym, group; void *d; };
+    struct TileList { int tiles_i, tiles_j, sym, group; void *d; int count; };
     std::vector<TileList> tile_lists;
 
     // grow-only scratch arena (top-k candidate lists, threshold sample)

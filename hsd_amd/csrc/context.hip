@@ -52,6 +52,7 @@ extern "C" int hsd_create(int device, hsd_ctx **out) {
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_flag), 4 * sizeof(int)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_work), sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_tile_ctr), 32 * sizeof(int)) != hipSuccess ||
         hipMemset(ctx->d_work, 0, sizeof(unsigned long long)) != hipSuccess) {
         hsd_destroy(ctx);          // releases whatever was created (all members start null)
         return HSD_ERR_HIP;
@@ -88,6 +89,7 @@ extern "C" void hsd_destroy(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_support);
     hsd_dev_free(ctx->d_flag);
     hsd_dev_free(ctx->d_work);
+    hsd_dev_free(ctx->d_tile_ctr);
     hsd_dev_free(ctx->d_stage);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (auto &t : ctx->tile_lists) (void)hipFree(t.d);

@@ -31,6 +31,9 @@ namespace {
 #ifndef HSD_PIN
 #define HSD_PIN 1
 #endif
+#ifndef HSD_F64_UNROLL
+#define HSD_F64_UNROLL 4            // columns per straight-line trip of the fp64 inner loops (2 = the plain two-column loop)
+#endif
 #if HSD_PIN
 #define HSD_PIN_ORDER __builtin_amdgcn_sched_barrier(0)
 #else
@@ -55,6 +58,8 @@ struct PairArgs {
     int64_t i_begin, i_end, j_begin, j_end;
     int tiles_i, tiles_j, ntiles;
     const int2 *tiles;      // optional explicit tile order (super-tile major), ntiles entries
+    int n_aux;              // persistent kernel: per-node vectors (1/ring size per layer, ring-0 value, entropy) staged through
+                            // LDS with every tile (0: read from global memory where they are needed)
     int sym;                // square region on the diagonal: only tiles on/above it are enumerated
     int mirror;             // also write the transposed tile (the region's mirror image belongs to this call)
     int swap;               // DOT below the diagonal: value(i,j) = H[j] - X_j . Y_i
@@ -66,6 +71,8 @@ struct PairArgs {
     int ngran;
     int list_cap;           // entries of the per-tile chunk list in LDS
     unsigned long long *work;   // += operand words x pairs evaluated (hsd_pair_work), or nullptr
+    int *tile_ctr;          // persistent kernel: [8] tiles drawn so far from each XCD's run (zeroed before the launch)
+    int ctr_slot;           // which of the context's counter sets this region uses (regions of a row block run side by side)
     int dbg;                // HSD_DEBUG ablation bits: 1 = no stores, 2 = no arithmetic
     // fused k-nearest consumer (hsd_pair_topk): instead of storing the tile, every value below its
     // row's threshold tau is appended to that row's candidate list
@@ -402,10 +409,11 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
         // instructions (WAIT_ANY 29 % of the wave cycles, profiles/r02a_target).
         // the scheduling barriers pin "request column c+1, THEN accumulate column c": without
         // them hipcc sinks the LDS reads below the arithmetic and waits for them at once
+        constexpr int UNR = sizeof(T) == 4 ? 8 : HSD_F64_UNROLL;      // (the fp64 kinds have few registers to spare)
 #pragma unroll 1
-        for (; c + 8 <= cvalid; c += 8) {
+        for (; UNR > 2 && c + UNR <= cvalid; c += UNR) {
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
+            for (int u = 0; u < UNR; u += 2) {
                 load_ops(min(c + u + 1, CH - 1), 1);
                 HSD_PIN_ORDER;
                 compute(0);
@@ -622,17 +630,19 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     T *sbase = reinterpret_cast<T *>(lds_raw);
     int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
-    int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths
+    int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths; [2]: the tile index drawn for the tile after next
+    // auxiliary per-node vectors of the current and the next tile: [2 tiles][n_aux][I: 128 doubles | J: 128 doubles]
+    // (vector v < n_seg: 1/ring size of layer v; then the ring-0 value or the entropy term)
+    double *aux = reinterpret_cast<double *>(nlist + 4);
+    constexpr int AUX_STRIDE = 256;                  // doubles per vector: one 1-KiB direct-to-LDS instruction per side
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double *)lds_raw);
 
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), l = threadIdx.x & 63;
     const int ly = l >> 3, lx = l & 7;
     const int wi = (NW == 4 ? (w >> 1) * 64 : 0) + 2 * ly, wj = (NW == 4 ? (w & 1) * 64 : 0) + 2 * lx;
     auto wg_barrier = [&]() __attribute__((always_inline)) {
-        if constexpr (NW > 1) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
     };
     const T *__restrict__ XI = reinterpret_cast<const T *>(a.swap ? a.Y : a.X);
     const T *__restrict__ XJ = reinterpret_cast<const T *>(a.swap ? a.X : a.Y);
@@ -647,8 +657,14 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     const int q = a.ntiles >> 3, rr = a.ntiles & 7;
     const int lo = x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q;
     const int hi = lo + (x < rr ? q + 1 : q);
+    // the first three tiles of a workgroup are fixed (lo + wx, + nwx, + 2 nwx); from then on it draws the next free tile of
+    // its XCD's run from a counter.  With a fixed share per workgroup the OLDER of the two workgroups of a CU wins every
+    // issue arbitration, finishes its share early (measured: half the workgroups ended at 137 ms, the other half at 232 ms)
+    // and leaves the CU half empty for the rest of the launch.
     int t = lo + wx;
     if (t >= hi) return;
+    int src = x;                                      // (wave 0, lane 0) the XCD whose counter this workgroup draws from; -1: all dry
+    const unsigned long long stamp0 = (a.dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // HSD_DEBUG bit 3: lifetime stamps
 
     // lane s keeps the description of layer segment s
     SegDesc sd{};
@@ -677,6 +693,20 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                      dst_lds + (uint32_t)((CH * BT + ins * COLS * BT) * sizeof(T)));
         }
         asm volatile("" ::: "memory");
+    };
+    // one 1-KiB instruction per vector and side (128 doubles; a 64-node tile uses the first half), dealt over the waves;
+    // issued in front of the tile's first chunk, so the wait for that chunk covers them
+    auto stage_aux = [&](int64_t ri0, int64_t rj0, int buf) __attribute__((always_inline)) -> int {
+        int issued = 0;
+        for (int v = 0; v < a.n_aux; ++v) {
+            if ((v & (NW - 1)) != w) continue;
+            gcdouble *src = v < a.n_seg ? ginv + (int64_t)v * a.npad : (gpoint ? gpoint : gH);
+            const uint32_t dst = lds_base + (uint32_t)(reinterpret_cast<char *>(aux + (buf * a.n_aux + v) * AUX_STRIDE) - reinterpret_cast<char *>(lds_raw));
+            glds16_s(reinterpret_cast<uint64_t>(src + ri0), 16u * l, dst);
+            glds16_s(reinterpret_cast<uint64_t>(src + rj0), 16u * l, dst + 1024u);
+            issued += 2;
+        }
+        return issued;
     };
     // raw ring maxima of the granules a tile touches (lane s: segment s); consumed one tile later
     auto issue_rmax = [&](int64_t ri0, int64_t rj0, uint32_t (&raw)[4]) __attribute__((always_inline)) {
@@ -734,18 +764,20 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     plan(raw, cur);
     if constexpr (SEG) { if constexpr (NW > 1) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     int n0 = planned_chunks(cur);
-    int t1 = t + nwx, t2 = t + 2 * nwx;
+    const int t1 = t + nwx, t2 = t + 2 * nwx;
+    bool has1 = t1 < hi, has2 = t2 < hi;
     int ti1 = 0, tj1 = 0, ti2 = 0, tj2 = 0;
-    if (t1 < hi) tile_from_index(a, t1, ti1, tj1);
-    if (t2 < hi) tile_from_index(a, t2, ti2, tj2);
+    if (has1) tile_from_index(a, t1, ti1, tj1);
+    if (has2) tile_from_index(a, t2, ti2, tj2);
     int64_t i1 = uniform64(a.i_begin + (int64_t)ti1 * BT), j1 = uniform64(a.j_begin + (int64_t)tj1 * BT);
     uint32_t raw1[4];
-    if (t1 < hi) issue_rmax(i1, j1, raw1);
+    if (has1) issue_rmax(i1, j1, raw1);
 
     int vm_seq = 0;                                   // vector-memory operations issued so far (lower bound: masked stores are not counted)
     int seq_of_stage[2] = {0, 0};                     // vm_seq right after the loads of the chunk that sits in each LDS stage
     int st = 0;                                       // LDS stage of the next chunk to be computed
     int ahead = 0;                                    // chunks of the current tile whose loads are already issued
+    vm_seq += stage_aux(i0, j0, cur);
     if (n0 > 0) { stage_chunk(chunk_col(cur, 0), i0, j0, 0); vm_seq += LOADS; seq_of_stage[0] = vm_seq; ahead = 1; }
     if (n0 > 1) { stage_chunk(chunk_col(cur, 1), i0, j0, 1); vm_seq += LOADS; seq_of_stage[1] = vm_seq; ahead = 2; }
     unsigned long long work = 0;
@@ -764,16 +796,18 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 for (int c = 0; c < TC; ++c) part[r][c] = (T)0;
         }
         // the next tile's plan: its ring maxima were requested one tile ago
-        const bool has1 = t1 < hi;
         int n1 = 0;
         if (has1) plan(raw1, cur ^ 1);
         wg_barrier();                                 // list of the next tile visible; every wave is done with the previous tile's LDS
         if (has1) n1 = planned_chunks(cur ^ 1);
-        // ... and the maxima of the tile after it are requested now
-        const bool has2 = t2 < hi;
+        // ... the maxima of the tile after it are requested now
         const int64_t i2 = uniform64(a.i_begin + (int64_t)ti2 * BT), j2 = uniform64(a.j_begin + (int64_t)tj2 * BT);
         if (has2) issue_rmax(i2, j2, raw1);            // (not counted in vm_seq: only operations that are certainly issued are)
+        // ... and the tile after that is drawn from the XCD's counter (the answer is picked up at the end of this tile)
+        int drawn = 0;
+        if (w == 0 && l == 0 && src >= 0) drawn = atomicAdd(a.tile_ctr + src, 1);
         int ahead1 = 0;                               // chunks of the NEXT tile already requested
+        bool aux1 = false;                            // ... and its auxiliary vectors
 
         for (int k = 0; k < n0; ++k) {
             int cvalid, seg = 0;
@@ -801,9 +835,13 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 if (ahead < n0) {
                     stage_chunk(chunk_col(cur, ahead), i0, j0, st ^ 1);
                     vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ++ahead;
-                } else if (ahead1 < n1 && ahead1 < 1) {
-                    stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st ^ 1);
-                    vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 1;
+                } else if (has1 && !aux1) {
+                    vm_seq += stage_aux(i1, j1, cur ^ 1);     // the next tile's vectors, then its first chunk
+                    aux1 = true;
+                    if (n1 > 0) {
+                        stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st ^ 1);
+                        vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 1;
+                    }
                 }
             }
             T av[2][TR], bv[2][TC];
@@ -835,10 +873,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             };
             load_ops(0, 0);
             int c = 0;
+            constexpr int UNR = sizeof(T) == 4 ? 8 : HSD_F64_UNROLL;
 #pragma unroll 1
-            for (; c + 8 <= cvalid; c += 8) {        // straight-line body: counted LDS waits (see pair_kernel)
+            for (; UNR > 2 && c + UNR <= cvalid; c += UNR) {        // straight-line body: counted LDS waits (see pair_kernel)
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) {
+                for (int u = 0; u < UNR; u += 2) {
                     load_ops(min(c + u + 1, CH - 1), 1);
                     HSD_PIN_ORDER;
                     compute(0);
@@ -864,12 +903,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             if constexpr (SEG) {
                 if (ends_seg) {
-                    gcdouble *invs = ginv + (int64_t)seg * a.npad;
                     double vi_[TR], vj_[TC];
+                    const double *ax = aux + (cur * a.n_aux + seg) * AUX_STRIDE;      // 1/ring size, staged with the tile
 #pragma unroll
-                    for (int cc = 0; cc < TC; ++cc) vj_[cc] = invs[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+                    for (int cc = 0; cc < TC; ++cc) vj_[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
-                    for (int r = 0; r < TR; ++r) vi_[r] = invs[i0 + wi + 16 * (r >> 1) + (r & 1)];
+                    for (int r = 0; r < TR; ++r) vi_[r] = ax[wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                     for (int r = 0; r < TR; ++r) {
                         const double vi = vi_[r];
@@ -884,7 +923,24 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             st ^= 1;
         }
         // the second chunk of the next tile goes out BEFORE this tile's stores: its loads then do not queue behind them
-        if constexpr (NW > 1) wg_barrier();           // the stage of the last chunk is free only when every wave has consumed it
+        if (w == 0 && l == 0) {
+            // position of the drawn tile in the order, or -1 when every run is exhausted.  A workgroup whose own XCD's run
+            // has run dry moves on to the next XCD's counter (the XCDs do not finish together: 217 .. 232 ms at BA N = 100k);
+            // those few draws are waited for on the spot
+            int pos = -1;
+            while (src >= 0) {
+                const int slo = src < rr ? src * (q + 1) : rr * (q + 1) + (src - rr) * q;
+                const int shi = slo + (src < rr ? q + 1 : q);
+                const int cand = slo + 3 * nwx + drawn;
+                if (cand < shi) { pos = cand; break; }
+                src = (src + 1) & 7;
+                if (src == x) { src = -1; break; }
+                drawn = atomicAdd(a.tile_ctr + src, 1);
+            }
+            nlist[2] = pos;
+        }
+        wg_barrier();                                 // the stage of the last chunk is free only when every wave has consumed it
+        if (has1 && !aux1) { vm_seq += stage_aux(i1, j1, cur ^ 1); aux1 = true; }
         if (ahead1 == 0 && n1 > 0) {
             stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st);
             vm_seq += LOADS; seq_of_stage[st] = vm_seq; ahead1 = 1;
@@ -894,15 +950,15 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 2;
         }
 
-        const bool diag = a.sym && ti == tj;
         // ---- epilogue arithmetic ----
         if constexpr (KIND == K_DOT) {
             double hj[TC];
+            const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) hj[cc] = gH[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+            for (int cc = 0; cc < TC; ++cc) hj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const double hi_ = gH[i0 + wi + 16 * (r >> 1) + (r & 1)];
+                const double hi_ = ax[wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
                     if (a.hmode == 0) acc[r][cc] = (a.swap ? hj[cc] : hi_) - acc[r][cc];
@@ -912,11 +968,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         }
         if (gpoint) {
             double pj[TC];
+            const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) pj[cc] = gpoint[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+            for (int cc = 0; cc < TC; ++cc) pj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const double pi = gpoint[i0 + wi + 16 * (r >> 1) + (r & 1)];
+                const double pi = ax[wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) acc[r][cc] += fabs(pi - pj[cc]);
             }
@@ -925,7 +982,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         asm volatile("" ::: "memory");
         if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
-        } else if (!diag && i0 + BT <= a.i_end && j0 + BT <= a.j_end) {
+        } else {
             gdouble *pd = out + (i0 + wi - a.rbase) * a.ld + (j0 + wj);
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
@@ -944,51 +1001,24 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 }
                 vm_seq += TR * TC / 2;
             }
-        } else {
-            // edge or diagonal tile: per-element masks (these stores are not counted in vm_seq: a lower bound is safe)
-            const int ilim = (int)min((int64_t)BT, a.i_end - i0), jlim = (int)min((int64_t)BT, a.j_end - j0);
-            gdouble *tb = out + (i0 - a.rbase) * a.ld + j0;
-#pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                int li = wi + 16 * (r >> 1) + (r & 1);
-                asm volatile("" : "+v"(li) :: "memory");
-                if (li >= ilim) continue;
-                gdouble *row = tb + (int64_t)li * a.ld;
-#pragma unroll
-                for (int qq = 0; qq < TC / 2; ++qq) {
-                    const int lj = wj + 16 * qq;
-                    const bool ok0 = lj < jlim && (!diag || li <= lj);
-                    const bool ok1 = lj + 1 < jlim && (!diag || li <= lj + 1);
-                    store2<true>(row + lj, (diag && li == lj) ? 0.0 : acc[r][2 * qq], (diag && li == lj + 1) ? 0.0 : acc[r][2 * qq + 1], ok0, ok1);
-                }
-            }
-            if (a.mirror) {
-                gdouble *mb = out + (j0 - a.rbase) * a.ld + i0;
-#pragma unroll
-                for (int cc = 0; cc < TC; ++cc) {
-                    int lj = wj + 16 * (cc >> 1) + (cc & 1);
-                    asm volatile("" : "+v"(lj) :: "memory");
-                    if (lj >= jlim) continue;
-                    gdouble *row = mb + (int64_t)lj * a.ld;
-#pragma unroll
-                    for (int qq = 0; qq < TR / 2; ++qq) {
-                        const int li = wi + 16 * qq;
-                        const bool ok0 = li < ilim && (!diag || li < lj);
-                        const bool ok1 = li + 1 < ilim && (!diag || li + 1 < lj);
-                        store2<true>(row + li, acc[2 * qq][cc], acc[2 * qq + 1][cc], ok0, ok1);
-                    }
-                }
-            }
         }
+        // (edge and diagonal tiles are not in this kernel's list: the one-tile kernel stores them with per-element masks)
         if (!has1) break;
         // ---- rotate: next tile becomes current ----
-        t = t1; t1 = t2; t2 += nwx;
-        ti = ti1; tj = tj1; ti1 = ti2; tj1 = tj2;
         i0 = i1; j0 = j1; i1 = i2; j1 = j2;
         n0 = n1; cur ^= 1; ahead = ahead1;
-        if (t2 < hi) tile_from_index(a, t2, ti2, tj2);
+        has1 = has2;
+        const int t3 = __builtin_amdgcn_readfirstlane(nlist[2]);
+        has2 = t3 >= 0;
+        if (has2) tile_from_index(a, t3, ti2, tj2);
     }
     if (a.work && threadIdx.x == 0) atomicAdd(a.work, work * (unsigned long long)(BT * BT));
+    if ((a.dbg & 8) && a.cand_val && threadIdx.x == 0) {
+        // measurement hook: (start, end) of this workgroup in 100 MHz ticks, in a buffer nothing else reads
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(a.cand_val) + 2 * (size_t)blockIdx.x;
+        st[0] = stamp0;
+        st[1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1199,23 +1229,32 @@ int tile_edge(const hsd_ctx *ctx) {
 // but with the rank form a tile of two young (low-degree) node blocks costs a fraction of a hub tile, and the XCD that
 // owned the cheap corner idled (wave occupancy 73-84 % at BA N = 100k, profiles/r02b).  HSD_XCD_DEAL=0: plain order.
 // nullptr (formula order in the kernel) when disabled or on allocation failure.
-const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym) {
+// cls: 0 = every tile; 1 = interior tiles only (off the diagonal of a symmetric region, not in a partial last row /
+// column: the persistent kernel's share); 2 = the others (stored with per-element masks by the one-tile kernel).
+const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls, bool part_i, bool part_j, int *count) {
     const char *e = getenv("HSD_SUPERTILE");
     const int S = e ? atoi(e) : 8;
-    if (S <= 1) return nullptr;
+    if (S <= 1 && cls == 0) { if (count) *count = -1; return nullptr; }
     const char *ed = getenv("HSD_XCD_DEAL");
     const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
-    const int key = S + (deal << 16);
+    const int key = std::max(S, 1) + (deal << 16) + (cls << 20) + ((int)part_i << 24) + ((int)part_j << 25);
     for (const auto &c : ctx->tile_lists)
-        if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == key) return reinterpret_cast<const int2 *>(c.d);
+        if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == key) {
+            if (count) *count = c.count;
+            return reinterpret_cast<const int2 *>(c.d);
+        }
+    const int G = std::max(S, 1);
     std::vector<int2> order;
     order.reserve(sym ? (size_t)tiles_i * (tiles_i + 1) / 2 : (size_t)tiles_i * tiles_j);
     std::vector<size_t> group_begin;
-    for (int sr = 0; sr < tiles_i; sr += S)
-        for (int sc = sym ? sr : 0; sc < tiles_j; sc += S) {
+    for (int sr = 0; sr < tiles_i; sr += G)
+        for (int sc = sym ? sr : 0; sc < tiles_j; sc += G) {
             group_begin.push_back(order.size());
-            for (int ti = sr; ti < std::min(sr + S, tiles_i); ++ti)
-                for (int tj = std::max(sc, sym ? ti : 0); tj < std::min(sc + S, tiles_j); ++tj) order.push_back(make_int2(ti, tj));
+            for (int ti = sr; ti < std::min(sr + G, tiles_i); ++ti)
+                for (int tj = std::max(sc, sym ? ti : 0); tj < std::min(sc + G, tiles_j); ++tj) {
+                    const bool masked = (sym && ti == tj) || (part_i && ti == tiles_i - 1) || (part_j && tj == tiles_j - 1);
+                    if (cls == 0 || (cls == 1) == !masked) order.push_back(make_int2(ti, tj));
+                }
         }
     group_begin.push_back(order.size());
     if (deal && group_begin.size() > 9) {
@@ -1226,11 +1265,16 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym) {
             for (size_t g = x; g < ng; g += 8) dealt.insert(dealt.end(), order.begin() + (long)group_begin[g], order.begin() + (long)group_begin[g + 1]);
         order.swap(dealt);
     }
+    if (count) *count = (int)order.size();
     void *d = nullptr;
-    if (hipMalloc(&d, order.size() * sizeof(int2)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    if (ctx->tile_lists.size() >= 8) { (void)hipFree(ctx->tile_lists.front().d); ctx->tile_lists.erase(ctx->tile_lists.begin()); }
-    ctx->tile_lists.push_back({tiles_i, tiles_j, sym, key, d});
+    if (hipMalloc(&d, std::max<size_t>(order.size(), 1) * sizeof(int2)) != hipSuccess) { if (count) *count = -1; return nullptr; }
+    if (!order.empty() && hipMemcpy(d, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        if (count) *count = -1;
+        return nullptr;
+    }
+    if (ctx->tile_lists.size() >= 12) { (void)hipFree(ctx->tile_lists.front().d); ctx->tile_lists.erase(ctx->tile_lists.begin()); }
+    ctx->tile_lists.push_back({tiles_i, tiles_j, sym, key, d, (int)order.size()});
     return reinterpret_cast<const int2 *>(d);
 }
 
@@ -1239,7 +1283,8 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     auto kern = pair_stream_kernel<KIND, NW>;
     constexpr int CH = stream_chunk_cols(KIND, NW);
     constexpr int BT = NW == 4 ? 128 : 64;
-    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16;
+    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 +
+                       (size_t)2 * a.n_aux * 256 * sizeof(double);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1255,26 +1300,68 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     }
     const int64_t resident = (int64_t)(per_cu / NW) * ctx->prop.multiProcessorCount / 8 * 8;
     const int grid = (int)std::min<int64_t>(resident, round_up(a.ntiles, 8));
+    {
+        hipError_t e = hipMemsetAsync(a.tile_ctr, 0, 8 * sizeof(int), stream);
+        if (e != hipSuccess) return e;
+    }
+    if (a.dbg & 8) {
+        // HSD_DEBUG bit 3: per-workgroup lifetimes -> stderr (synchronises; measurement only)
+        PairArgs b = a;
+        unsigned long long *d_st = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d_st), (size_t)grid * 16) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d_st, 0, (size_t)grid * 16);
+        b.cand_val = reinterpret_cast<double *>(d_st);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, b);
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 2);
+        (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_st);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int g = 0; g < grid; ++g) if (h[2 * g]) { t0 = std::min(t0, h[2 * g]); t1 = std::max(t1, h[2 * g + 1]); }
+        std::vector<double> life, endt;
+        for (int g = 0; g < grid; ++g) if (h[2 * g]) { life.push_back((h[2 * g + 1] - h[2 * g]) * 1e-2); endt.push_back((h[2 * g + 1] - t0) * 1e-2); }
+        std::sort(endt.begin(), endt.end());
+        double per_xcd[8] = {0};
+        int cnt[8] = {0};
+        for (int g = 0; g < grid; ++g) if (h[2 * g]) { per_xcd[g & 7] += (h[2 * g + 1] - t0) * 1e-2; ++cnt[g & 7]; }
+        fprintf(stderr, "[hsd stream<%d,%d>] %zu workgroups, span %.1f us; end times us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f; mean end per b%%8:", KIND, NW,
+                endt.size(), (t1 - t0) * 1e-2, endt.front(), endt[endt.size() / 10], endt[endt.size() / 2], endt[endt.size() * 9 / 10], endt.back());
+        for (int x8 = 0; x8 < 8; ++x8) fprintf(stderr, " %.0f", cnt[x8] ? per_xcd[x8] / cnt[x8] : 0.0);
+        fprintf(stderr, "\n");
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
 }
 
-// The persistent kernels take every region whose operand slices and output rows are 16-byte aligned (direct-to-LDS
+// The persistent kernel takes every region whose operand slices and output rows are 16-byte aligned (direct-to-LDS
 // loads, vector stores), except the fused k-nearest consumer and the fp64 zero-pad fallback (its two fp64 accumulator
-// sets do not fit 8 x 8 pairs per lane).  HSD_STREAM=0: the one-tile-per-workgroup kernel; 1: one wave per workgroup
-// (64 x 64 tiles); 4: four waves (128 x 128 tiles).
+// sets do not fit 8 x 8 pairs per lane).  HSD_STREAM=0 or an explicit HSD_TILE: the one-tile-per-workgroup kernel for
+// every tile (A/B measurements; the tests run both and compare them bit for bit).
 int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
-    const char *ew = getenv("HSD_STREAM");
-    const int nw = ew ? atoi(ew) : 0;
-    if (nw != 1 && nw != 4) return 0;
-    if (getenv("HSD_TILE")) return 0;               // an explicit tile shape asks for the one-tile kernel
+    if (const char *ew = getenv("HSD_STREAM")) if (atoi(ew) == 0) return 0;
+    if (getenv("HSD_TILE")) return 0;
     if (a.tau || ctx->mode == PAIR_ZP_F64) return 0;
     const bool aligned = (a.i_begin % 4 == 0) && (a.j_begin % 4 == 0) && (a.npad % 4 == 0) && (a.ld % 2 == 0) &&
                          (reinterpret_cast<uintptr_t>(a.out) % 16 == 0);
-    return aligned ? nw : 0;
+    return aligned ? 4 : 0;
+}
+
+hipError_t launch_one_tile(hsd_ctx *ctx, const PairArgs &a, int BT, hipStream_t stream) {
+    const int g = a.ntiles;
+    switch (ctx->mode) {
+        case PAIR_L1_F64: return BT == 128 ? launch_kind<K_L1, 8>(ctx, a, g, stream) : launch_kind<K_L1, 4>(ctx, a, g, stream);
+        case PAIR_SAD_U32: return BT == 128 ? launch_kind<K_SAD, 8>(ctx, a, g, stream) : launch_kind<K_SAD, 4>(ctx, a, g, stream);
+        case PAIR_SAD_U16: return BT == 128 ? launch_kind<K_SAD16, 8>(ctx, a, g, stream) : launch_kind<K_SAD16, 4>(ctx, a, g, stream);
+        case PAIR_ZP_F64: return launch_kind<K_ZP, 4>(ctx, a, g, stream);      // fallback kind: 64 x 64 only
+        case PAIR_KL:
+        case PAIR_SKL: return BT == 128 ? launch_kind<K_DOT, 8>(ctx, a, g, stream) : launch_kind<K_DOT, 4>(ctx, a, g, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
+    if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     const int nw = stream_waves(ctx, a);
     if (nw) BT = nw == 4 ? 128 : 64;
     a.tiles_i = (int)((a.i_end - a.i_begin + BT - 1) / BT);
@@ -1282,31 +1369,46 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
     if (a.tiles_i <= 0 || a.tiles_j <= 0) return HSD_OK;
     const int64_t nb = a.sym ? (int64_t)a.tiles_i * (a.tiles_i + 1) / 2 : (int64_t)a.tiles_i * a.tiles_j;
     if (nb > 0x7fffffff) return hsd_fail(ctx, HSD_ERR_TOO_LARGE, "too many tiles (%lld)", (long long)nb);
-    a.ntiles = (int)nb;
-    const int g = (int)nb;
-    a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym);
-    hipError_t e;
+    const bool part_i = (a.i_end - a.i_begin) % BT != 0, part_j = (a.j_end - a.j_begin) % BT != 0;
+    hipError_t e = hipSuccess;
     if (nw) {
-        switch (ctx->mode) {
-            case PAIR_L1_F64: e = nw == 4 ? launch_stream<K_L1, 4>(ctx, a, stream) : launch_stream<K_L1, 1>(ctx, a, stream); break;
-            case PAIR_SAD_U32: e = nw == 4 ? launch_stream<K_SAD, 4>(ctx, a, stream) : launch_stream<K_SAD, 1>(ctx, a, stream); break;
-            case PAIR_SAD_U16: e = nw == 4 ? launch_stream<K_SAD16, 4>(ctx, a, stream) : launch_stream<K_SAD16, 1>(ctx, a, stream); break;
-            case PAIR_KL:
-            case PAIR_SKL: e = nw == 4 ? launch_stream<K_DOT, 4>(ctx, a, stream) : launch_stream<K_DOT, 1>(ctx, a, stream); break;
-            default: return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
+        // interior tiles: the persistent kernel; diagonal and partial tiles: the one-tile kernel with its masked stores
+        // (the two launches write disjoint tiles; the second is tiny and runs in the tail of the first)
+        int n_in = -1, n_mask = -1;
+        const int2 *l_in = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 1, part_i, part_j, &n_in);
+        const int2 *l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 2, part_i, part_j, &n_mask);
+        if (n_in >= 0 && n_mask >= 0) {
+            const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
+            PairArgs b = a;
+            b.tile_ctr = ctx->d_tile_ctr + 8 * (a.ctr_slot & 3);
+            b.n_aux = ctx->n_seg + ((wass ? a.point != nullptr : true) ? 1 : 0);
+            // LDS budget of the persistent kernel (2 workgroups per CU): two tiles x three vectors x 2 KiB; deeper hierarchies
+            // (more than two compared histogram layers + ring 0) take the one-tile kernel for every tile
+            if (b.n_aux > 3) { n_mask += n_in; n_in = 0; l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &n_mask); }
+            if (n_in > 0) {
+                b.tiles = l_in;
+                b.ntiles = n_in;
+                switch (ctx->mode) {
+                    case PAIR_L1_F64: e = launch_stream<K_L1, 4>(ctx, b, stream); break;
+                    case PAIR_SAD_U32: e = launch_stream<K_SAD, 4>(ctx, b, stream); break;
+                    case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4>(ctx, b, stream); break;
+                    default: e = launch_stream<K_DOT, 4>(ctx, b, stream); break;
+                }
+            }
+            if (e == hipSuccess && n_mask > 0) {
+                PairArgs c = a;
+                c.tiles = l_mask;
+                c.ntiles = n_mask;
+                e = launch_one_tile(ctx, c, BT, stream);
+            }
+            if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
+            return HSD_OK;
         }
-        if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
-        return HSD_OK;
+        // (list allocation failed: fall through to the one-tile kernel over every tile)
     }
-    switch (ctx->mode) {
-        case PAIR_L1_F64: e = BT == 128 ? launch_kind<K_L1, 8>(ctx, a, g, stream) : launch_kind<K_L1, 4>(ctx, a, g, stream); break;
-        case PAIR_SAD_U32: e = BT == 128 ? launch_kind<K_SAD, 8>(ctx, a, g, stream) : launch_kind<K_SAD, 4>(ctx, a, g, stream); break;
-        case PAIR_SAD_U16: e = BT == 128 ? launch_kind<K_SAD16, 8>(ctx, a, g, stream) : launch_kind<K_SAD16, 4>(ctx, a, g, stream); break;
-        case PAIR_ZP_F64: e = launch_kind<K_ZP, 4>(ctx, a, g, stream); break;      // fallback kind: 64 x 64 only
-        case PAIR_KL:
-        case PAIR_SKL: e = BT == 128 ? launch_kind<K_DOT, 8>(ctx, a, g, stream) : launch_kind<K_DOT, 4>(ctx, a, g, stream); break;
-        default: return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    }
+    a.ntiles = (int)nb;
+    a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, nullptr);
+    e = launch_one_tile(ctx, a, BT, stream);
     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
     return HSD_OK;
 }
@@ -1799,6 +1901,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
         const int BT = tile_edge(ctx);
         auto rect = [&](int t, int64_t jb, int64_t je, int swap) -> int {
             b.j_begin = jb; b.j_end = je; b.swap = swap;
+            b.ctr_slot = t + 1;
             if (!fork) return launch_region(ctx, b, BT, ctx->stream);
             HSD_HIP(ctx, hipStreamWaitEvent(ctx->side[t], ctx->ev_fork, 0));
             const int r = launch_region(ctx, b, BT, ctx->side[t]);

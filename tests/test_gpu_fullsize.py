@@ -278,7 +278,9 @@ def test_config5_multihsd_ba50k_full_size(engine):
             # an entry within rounding of the 1e-4/N = 2e-9 threshold may be kept by one side only: each flip moves
             # a ring sum by at most 2e-9
             assert np.allclose(got, ref, rtol=1e-6, atol=2e-8), (si, u, got, ref)
-    # ring 0 is the node itself: sum == mean == psi[i, i] in (0, 1]; sums over all rings of one scale are <= 1
+    # ring 0 is the node itself: sum == mean == psi[i, i], positive at the small scales (at the large ones the order-50
+    # polynomial falls below the 1e-4/N threshold and the entry is zeroed, as in the reference); thresholded entries are
+    # never negative and the rings of one scale hold at most the whole row (sum 1)
     for u in nodes:
         e = np.asarray(emb[u]).reshape(S, K + 1, 2)
-        assert np.all(e[:, 0, 0] == e[:, 0, 1]) and np.all(e[:, 0, 0] > 0) and np.all(e[:, :, 0].sum(axis=1) <= 1 + 1e-9)
+        assert np.all(e[:, 0, 0] == e[:, 0, 1]) and e[0, 0, 0] > 0 and np.all(e >= 0) and np.all(e[:, :, 0].sum(axis=1) <= 1 + 1e-6)
