@@ -14,6 +14,31 @@
 
 namespace {
 
+// sum over CSR entries [b, e) of val[p] * Tcur[col[p] * C + c], added in entry order; the gathers of eight entries are
+// issued together.  Measured on BA N = 50k (config 5, one box, tools_dev/cfg5.py): this form 2.08-2.10 s; one wave per row
+// with 16-byte gathers 2.39-2.40 s; one workgroup per row with two columns (16 bytes) per thread 2.36-2.39 s.  The step
+// moves (nnz + 2 N) C 8 bytes through the L2-miss path at 3-4 TB/s whatever the access shape: the neighbour rows of a
+// scale-free graph are all over the 100 MB plane, so the XCD L2s (4 MB) only keep the hubs.
+__device__ inline double gather_row_dot(const int32_t *__restrict__ col, const double *__restrict__ val, int64_t b, int64_t e,
+                                        const double *__restrict__ Tcur, int64_t C, int64_t c, double t) {
+    int64_t p = b;
+    for (; p + 8 <= e; p += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = Tcur[(int64_t)col[p + u] * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t = fma(val[p + u], x[u], t);
+    }
+    if (p < e) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (p + u < e) ? Tcur[(int64_t)col[p + u] * C + c] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (p + u < e) t = fma(val[p + u], x[u], t);
+    }
+    return t;
+}
+
 // ---- Laplacian SpMM step of the Chebyshev recurrence -------------------------------------
 // T_new = alpha * (L T_cur) + beta * T_cur + gamma * T_old ;  R += ck * T_new
 // Dense blocks are node-major [n][C] (C = impulse columns of this block) so that one CSR
@@ -35,7 +60,7 @@ __global__ __launch_bounds__(256) void cheby_step_kernel(const int64_t *__restri
             // long row: its chunks were multiplied by cheby_partial_kernel; add them in chunk order
             for (int q = 0; q < nch; ++q) t += partial[(int64_t)(chunk0 + q) * C + c];
         } else {
-            for (int64_t p = b; p < e; ++p) t = fma(val[p], Tcur[(int64_t)col[p] * C + c], t);
+            t = gather_row_dot(col, val, b, e, Tcur, C, c, t);
         }
         const double cur = Tcur[i * C + c];
         double v = alpha * t + beta * cur;
@@ -53,9 +78,7 @@ __global__ __launch_bounds__(256) void cheby_partial_kernel(const int64_t *__res
     const int64_t q = blockIdx.x;
     const int64_t b = chunk_p0[q], e = min(b + HSD_LCHUNK, rowptr[chunk_row[q] + 1]);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double t = 0.0;
-        for (int64_t p = b; p < e; ++p) t = fma(val[p], Tcur[(int64_t)col[p] * C + c], t);
-        partial[q * C + c] = t;
+        partial[q * C + c] = gather_row_dot(col, val, b, e, Tcur, C, c, 0.0);
     }
 }
 
@@ -110,8 +133,7 @@ __global__ __launch_bounds__(256) void cheby_step_multi_kernel(const int64_t *__
     const int64_t i = blockIdx.x;
     const int64_t b = rowptr[i], e = rowptr[i + 1];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double t = 0.0;
-        for (int64_t p = b; p < e; ++p) t = fma(val[p], Tcur[(int64_t)col[p] * C + c], t);
+        const double t = gather_row_dot(col, val, b, e, Tcur, C, c, 0.0);
         const double cur = Tcur[i * C + c];
         double v = alpha * t + beta * cur;
         if (!first) v += gamma * Told[i * C + c];
