@@ -206,15 +206,43 @@ __device__ inline void store2_full(gdouble *p, double v0, double v1, bool nt) {
     }
 }
 
-// One layer ("segment") of a zero-pad distance has two exact representations of the same integer
+// One layer ("segment") of a zero-pad distance has exact representations of the same integer
 //   S(i, j) = |n_i - n_j| s_0 + sum_b |T_i(b) - T_j(b)| (s_{b+1} - s_b)  =  sum_r |u_i(r) - u_j(r)|
-// (area between the two tail-count step functions = L1 distance of the descending sorted samples, zero padded):
-//   bin form   one column per support bin (tail count x bin width)          -> bin_words words, every tile pair
-//   rank form  one column per rank r (r-th largest member value, 0 beyond)  -> ceil(R / 2) words, R = largest ring
-//              of the layer among the nodes of the two tiles
-// A tile pair evaluates whichever is shorter: sparse layers (ring 1 of a scale-free graph: 10 members against 241
-// degree bins) cost a few words instead of 120.  Same integer, so the result is bit-identical either way.
-struct SegDesc : HsdSegDesc {};    // columns in words; rank_col0 < 0: no rank form
+// (area between the two tail-count step functions T(x) = #members > x  =  L1 distance of the descending sorted samples,
+// zero padded), and the area may be cut at any value theta and each part taken in either form:
+//   bin form   one column per support bin (tail count x bin width), two uint16 columns per word
+//   rank form  one column per rank r: (r-th largest member value - theta)+, zeros beyond the members above theta
+//              -> ceil(R / 2) words, R = most members above theta among the nodes of the two tiles
+// A layer is stored as: bin columns below theta (always evaluated), bin columns above theta, and rank columns above theta; a
+// tile pair takes whichever of the last two is shorter.  theta = 0 is the pure rank form (ring 1 of a scale-free graph:
+// ~10 members against 241 degree bins); ring 2 (hundreds of members, a few dozen of them hubs) keeps the dense low bins
+// and takes its sparse tail by rank.  Same integer either way, so the result is bit-identical.
+struct SegDesc : HsdSegDesc {};    // columns in words
+
+// Lane l < n_seg holds segment l: choose the form of its upper part from R (members above theta, worst node of the tile
+// pair), then the lanes append their chunks {first column, valid | ends_segment << 8 | segment << 16} to the tile's list.
+// Returns the inclusive prefix of the chunk counts (lane 63: the list length).
+template <int CH, bool PACK>
+__device__ inline int plan_segment(const SegDesc &sd, bool active, uint32_t R, int l, int2 *lst) {
+    int lc = sd.low_col0, lw = active ? sd.low_words : 0, hc = sd.hi_col0, hw = active ? sd.hi_words : 0;
+    if (active && sd.rank_col0 >= 0) {
+        const int wr = PACK ? (int)((R + 1) >> 1) : (int)R;
+        if (wr <= sd.rank_cap) { hc = sd.rank_col0; hw = wr; }
+    }
+    const int nlo = (lw + CH - 1) / CH, nhi = (hw + CH - 1) / CH, nch = nlo + nhi;
+    int pre = nch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(pre, o, 64);
+        if (l >= o) pre += up;
+    }
+    int2 *dst = lst + (pre - nch);
+    for (int c = 0; c < nlo; ++c)
+        dst[c] = make_int2(lc + c * CH, min(CH, lw - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+    for (int c = 0; c < nhi; ++c)
+        dst[nlo + c] = make_int2(hc + c * CH, min(CH, hw - c * CH) | ((nlo + c == nch - 1) ? 0x100 : 0) | (l << 16));
+    return pre;
+}
 
 // A workgroup computes exactly one tile.
 template <int KIND, bool FAST, int TR>
@@ -258,31 +286,19 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
     int nchunks = a.dcols / CH;
     if constexpr (SEG) {
         if (w == 0) {
-            // lane s decides segment s: bin form, or rank form if the largest ring of the layer among the nodes of
-            // both tiles needs fewer words (rmax: per 64-node granule maxima of the ring sizes)
-            int col0 = 0, words = 0;
-            if (l < a.n_seg) {
-                const SegDesc sd = a.seg_tab[l];
-                col0 = sd.bin_col0;
-                words = sd.bin_words;
+            // lane s plans segment s (rmax: per 64-node granule maxima of the members above the segment's threshold)
+            SegDesc sd{};
+            uint32_t R = 0;
+            const bool active = l < a.n_seg;
+            if (active) {
+                sd = a.seg_tab[l];
                 if (sd.rank_col0 >= 0) {
                     const uint32_t *rm = a.rmax + (int64_t)l * a.ngran;
-                    uint32_t R = 0;
                     for (int64_t g = i0 >> 6; g <= (i0 + BT - 1) >> 6; ++g) R = max(R, rm[g]);
                     for (int64_t g = j0 >> 6; g <= (j0 + BT - 1) >> 6; ++g) R = max(R, rm[g]);
-                    const int wr = (KIND == K_SAD16) ? (int)((R + 1) >> 1) : (int)R;
-                    if (wr <= sd.rank_cap) { col0 = sd.rank_col0; words = wr; }
                 }
             }
-            const int nch = (words + CH - 1) / CH;
-            int pre = nch;                            // inclusive prefix over the lanes = end of this segment's chunks
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(pre, o, 64);
-                if (l >= o) pre += up;
-            }
-            for (int c = 0; c < nch; ++c)
-                clist[pre - nch + c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+            const int pre = plan_segment<CH, KIND == K_SAD16>(sd, active, R, l, clist);
             if (l == 63) *nlist_p = pre;
         }
         __syncthreads();
@@ -726,22 +742,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     auto plan = [&](const uint32_t (&raw)[4], int buf) __attribute__((always_inline)) {
         if constexpr (SEG) {
             if (w != 0) return;
-            int col0 = sd.bin_col0, words = (l < a.n_seg) ? sd.bin_words : 0;
-            if (sd.rank_col0 >= 0) {
-                const uint32_t R = max(max(raw[0], raw[1]), max(raw[2], raw[3]));
-                const int wr = (KIND == K_SAD16) ? (int)((R + 1) >> 1) : (int)R;
-                if (wr <= sd.rank_cap) { col0 = sd.rank_col0; words = wr; }
-            }
-            const int nch = (words + CH - 1) / CH;
-            int pre = nch;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(pre, o, 64);
-                if (l >= o) pre += up;
-            }
-            int2 *lst = clist + buf * a.list_cap;
-            for (int c = 0; c < nch; ++c)
-                lst[pre - nch + c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+            const uint32_t R = max(max(raw[0], raw[1]), max(raw[2], raw[3]));
+            const int pre = plan_segment<CH, KIND == K_SAD16>(sd, l < a.n_seg, R, l, clist + buf * a.list_cap);
             if (l == 63) nlist[buf] = pre;
         }
     };
@@ -1099,25 +1101,27 @@ __global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict
     }
 }
 
-// Rank form of a zero-pad layer (SegDesc): word w of node i holds the (2w)-th and (2w+1)-th largest member values of
-// the ring (PACK: two uint16 per word; else one uint32 per word), zeros beyond the ring's size.  The histogram is
-// walked from the top bin down; only the first `cap` words are kept (longer rings use the bin form).
+// Rank columns of a zero-pad layer above its threshold (SegDesc): word w of node i holds the (2w)-th and (2w+1)-th largest
+// of (member value - theta) over the members with bin index >= first_bin (PACK: two uint16 per word; else one uint32 per
+// word), zeros beyond them.  The histogram is walked from the top bin down; only the first `cap` words are kept (tile pairs
+// that would need more take the bin columns).
 template <bool PACK>
 __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_col0, const int *__restrict__ seg_rank_cap,
-                                 uint32_t *__restrict__ X) {
+                                 const int *__restrict__ seg_first_bin, uint32_t *__restrict__ X) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
     const int sgi = blockIdx.y;
     const int k = first + sgi;
     if (i >= p.n || seg_rank_col0[sgi] < 0) return;
     const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    const int cap = seg_rank_cap[sgi];
+    const int cap = seg_rank_cap[sgi], fb = seg_first_bin[sgi];
+    const uint32_t theta = fb > 0 ? (uint32_t)p.support[fb - 1] : 0u;
     uint32_t *col = X + (int64_t)seg_rank_col0[sgi] * p.npad + i;
     const int want = PACK ? 2 * cap : cap;           // values to emit
     int r = 0;
     uint32_t lo = 0;
-    for (int b = p.B - 1; b >= 0 && r < want; --b) {
-        const uint32_t v = (uint32_t)p.support[b];
+    for (int b = p.B - 1; b >= fb && r < want; --b) {
+        const uint32_t v = (uint32_t)p.support[b] - theta;
         for (uint32_t m = c[b]; m > 0 && r < want; --m, ++r) {
             if (PACK) {
                 if (r & 1) col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16);
@@ -1128,6 +1132,22 @@ __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_co
         }
     }
     if (PACK && (r & 1)) col[(int64_t)(r >> 1) * p.npad] = lo;      // odd count: upper half stays 0
+}
+
+// above[(s * n_cand + q) * npad + i] = members of ring layer s of node i with bin index >= cand_bin[q]
+__global__ void count_above_kernel(PrepArgs p, const int *__restrict__ cand_bin, int n_cand, uint32_t *__restrict__ above) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
+    const int sgi = blockIdx.y;
+    if (i >= p.n) return;
+    const uint32_t *c = p.counts + ((int64_t)i * p.L + first + sgi) * p.B;
+    uint32_t run = 0;
+    int q = n_cand - 1;
+    for (int b = p.B - 1; b >= 0; --b) {
+        while (q >= 0 && cand_bin[q] > b) { above[((int64_t)sgi * n_cand + q) * p.npad + i] = run; --q; }
+        run += c[b];
+    }
+    for (; q >= 0; --q) above[((int64_t)sgi * n_cand + q) * p.npad + i] = run;
 }
 
 // rmax[s][g] = largest ring size of layer segment s within the 64-node granule g
@@ -1629,7 +1649,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `two` leaves scope
     }
     HsdSegDesc *tab = ctx->seg_tab;
-    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0};
+    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{0, 0, s * stride, B, -1, 0};
     ctx->dcols_alg = nl_hist * B;
 
     if (!use_u32 || nl_hist == 0) {
@@ -1646,10 +1666,8 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax, (size_t)nl_hist * ngran))) return rc;
         ctx->ngran = ngran;
         hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)ncol32), dim3(256), 0, ctx->stream, x0.as<uint32_t>(), npad, cmaxd.as<uint32_t>());
-        hipLaunchKernelGGL(granule_max_kernel, dim3((unsigned)ngran, (unsigned)nl_hist), dim3(64), 0, ctx->stream, ntot.as<uint32_t>(), npad, ngran, ctx->d_rmax);
-        std::vector<uint32_t> cmax((size_t)ncol32), rmax((size_t)nl_hist * ngran);
+        std::vector<uint32_t> cmax((size_t)ncol32);
         HSD_HIP(ctx, hipMemcpyAsync(cmax.data(), cmaxd.p, cmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HSD_HIP(ctx, hipMemcpyAsync(rmax.data(), ctx->d_rmax, rmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
         // uint16 packing: two columns per word, one v_sad_u16 covers both.  A column whose values (tail count x bin
@@ -1679,28 +1697,90 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         const int bin_words = pack ? (V + 1) / 2 : B;
         const int bin_stride = (int)round_up(bin_words, CH);
 
-        // rank form per layer: worth storing when some 64-node granule's largest ring needs fewer words than the bin form
+        // Threshold and rank columns per layer.  Candidates: theta = 0 (pure rank form) and the bin boundaries that fall on a
+        // word boundary of the packed bin columns nearest to eighths of the support.  For each, the members above theta of
+        // every node -> maxima per 64-node granule -> expected words per tile pair
+        //   low words + E[ rank words if they fit the cap, else the upper bin words ]
+        // over all granule pairs (exact from the sorted maxima); the cheapest candidate is stored, or none if nothing
+        // beats the plain bin form by 3 %.
         const char *er = getenv("HSD_RANK");
-        bool rank_ok = !(er && atoi(er) == 0);
+        const int rank_mode = er ? atoi(er) : 2;                // 0: bin form only; 1: theta = 0 only; 2: any threshold
+        bool rank_ok = rank_mode != 0;
         if (pack && ctx->support.back() >= 65536.0) rank_ok = false;      // member values must fit a uint16 half
+        const auto words_of = [&](uint32_t R) { return pack ? (int64_t)((R + 1) / 2) : (int64_t)R; };
+        // first packed word of raw column r (columns are split into virtual ones for packing): word boundary iff even
+        std::vector<int> vfirst((size_t)B + 1, V);
+        if (pack) { for (int v = V - 1; v >= 0; --v) vfirst[(size_t)vsrc[(size_t)v]] = v; vfirst[(size_t)B] = V; }
+        else for (int r = 0; r <= B; ++r) vfirst[(size_t)r] = r;
+        std::vector<int> cand;                                  // raw column index r*: columns [0, r*) stay in bin form
+        cand.push_back(0);
+        if (rank_mode >= 2)
+            for (int e8 = 1; e8 < 8; ++e8) {
+                int r = std::max(1, e8 * B / 8);
+                while (r < B && pack && (vfirst[(size_t)r] & 1)) ++r;     // packed: the cut must fall between two words
+                if (r < B && r > cand.back()) cand.push_back(r);
+            }
+        const int NC = (int)cand.size();
+        std::vector<uint32_t> gmax;                             // [nl_hist][NC][ngran]
+        if (rank_ok) {
+            // column r >= 1 is the interval [s_{r-1}, s_r): members above theta = s_{r*-1} are those in bins >= r*
+            DevTmp dcand, dabove, dgm;
+            HSD_TMP_ALLOC(ctx, dcand, (size_t)NC * sizeof(int));
+            HSD_TMP_ALLOC(ctx, dabove, (size_t)nl_hist * NC * npad * sizeof(uint32_t));
+            HSD_TMP_ALLOC(ctx, dgm, (size_t)nl_hist * NC * ngran * sizeof(uint32_t));
+            HSD_HIP(ctx, hipMemcpyAsync(dcand.p, cand.data(), (size_t)NC * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HSD_HIP(ctx, hipMemsetAsync(dabove.p, 0, (size_t)nl_hist * NC * npad * sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(count_above_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nl_hist), block, 0, ctx->stream, p, dcand.as<int>(), NC,
+                               dabove.as<uint32_t>());
+            hipLaunchKernelGGL(granule_max_kernel, dim3((unsigned)ngran, (unsigned)(nl_hist * NC)), dim3(64), 0, ctx->stream, dabove.as<uint32_t>(), npad,
+                               ngran, dgm.as<uint32_t>());
+            gmax.resize((size_t)nl_hist * NC * ngran);
+            HSD_HIP(ctx, hipMemcpyAsync(gmax.data(), dgm.p, gmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // temporaries leave scope
+        }
         int col = nl_hist * bin_stride;
         int list_cap = 1;
+        std::vector<int> first_bin((size_t)nl_hist, 0);
+        std::vector<uint32_t> rmax_sel((size_t)nl_hist * ngran, 0u);
+        const int64_t G = (n + 63) / 64;
         for (int sgi = 0; sgi < nl_hist; ++sgi) {
-            tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0};
-            list_cap += (bin_words + 7) / 8 + 1;        // either kernel: chunks of 32 / 16 words (uint32) or 16 / 8 columns (fp64)
+            tab[sgi] = HsdSegDesc{0, 0, sgi * bin_stride, bin_words, -1, 0};      // everything in the "upper" bin part
+            list_cap += (bin_words + 7) / 8 + 2;        // either kernel: chunks of 32 / 16 words (uint32) or 16 / 8 columns (fp64)
             if (!rank_ok || bin_words < 2) continue;
-            uint32_t rmin = 0xffffffffu, rall = 0;
-            for (int64_t g = 0; g < (n + 63) / 64; ++g) {
-                rmin = std::min(rmin, rmax[(size_t)sgi * ngran + g]);
-                rall = std::max(rall, rmax[(size_t)sgi * ngran + g]);
+            double best_cost = 0.97 * bin_words;
+            int best_q = -1, best_cap = 0;
+            std::vector<uint32_t> sorted((size_t)G);
+            for (int q = 0; q < NC; ++q) {
+                const uint32_t *gm = gmax.data() + ((size_t)sgi * NC + q) * ngran;
+                std::copy(gm, gm + G, sorted.begin());
+                std::sort(sorted.begin(), sorted.end());
+                const int low_w = vfirst[(size_t)cand[(size_t)q]] / (pack ? 2 : 1), hi_w = bin_words - low_w;
+                if (hi_w < 2) continue;
+                const int cap = (int)std::min<int64_t>(hi_w - 1, words_of(sorted.back()));
+                // E over unordered granule pairs of f(max): the k-th smallest (0-based) is the maximum of k + 1 pairs
+                long double acc = 0.0L;
+                for (int64_t k2 = 0; k2 < G; ++k2) {
+                    const int64_t wr = words_of(sorted[(size_t)k2]);
+                    acc += (long double)(wr <= cap ? wr : hi_w) * (long double)(k2 + 1);
+                }
+                const double cost = low_w + (double)(acc / ((long double)G * (G + 1) / 2));
+                if (cost < best_cost) { best_cost = cost; best_q = q; best_cap = cap; }
             }
-            const auto words_of = [&](uint32_t R) { return pack ? (int64_t)((R + 1) / 2) : (int64_t)R; };
-            if (words_of(rmin) >= bin_words) continue;           // no tile pair would ever choose it
-            const int cap = (int)std::min<int64_t>(bin_words - 1, words_of(rall));
+            if (best_q < 0) continue;
+            const int low_w = vfirst[(size_t)cand[(size_t)best_q]] / (pack ? 2 : 1);
+            tab[sgi].low_col0 = sgi * bin_stride;
+            tab[sgi].low_words = low_w;
+            tab[sgi].hi_col0 = sgi * bin_stride + low_w;
+            tab[sgi].hi_words = bin_words - low_w;
             tab[sgi].rank_col0 = col;
-            tab[sgi].rank_cap = cap;
-            col += (int)round_up(cap, CH);
+            tab[sgi].rank_cap = best_cap;
+            first_bin[(size_t)sgi] = cand[(size_t)best_q];
+            std::copy(gmax.data() + ((size_t)sgi * NC + best_q) * ngran, gmax.data() + ((size_t)sgi * NC + best_q + 1) * ngran,
+                      rmax_sel.begin() + (size_t)sgi * ngran);
+            col += (int)round_up(best_cap, CH);
         }
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax, rmax_sel.data(), rmax_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // rmax_sel is a local
         ctx->list_cap = list_cap;
         ctx->dcols = std::max(col, CH);
         ctx->dcols_alg = nl_hist * bin_words;
@@ -1732,20 +1812,23 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         for (int sgi = 0; sgi < nl_hist; ++sgi) any_rank |= tab[sgi].rank_col0 >= 0;
         if (any_rank) {
             DevTmp dr;
-            std::vector<int> rc0((size_t)nl_hist), rcap((size_t)nl_hist);
-            for (int sgi = 0; sgi < nl_hist; ++sgi) { rc0[(size_t)sgi] = tab[sgi].rank_col0; rcap[(size_t)sgi] = tab[sgi].rank_cap; }
-            HSD_TMP_ALLOC(ctx, dr, (size_t)2 * nl_hist * sizeof(int));
-            HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), (size_t)nl_hist * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            HSD_HIP(ctx, hipMemcpyAsync(dr.as<int>() + nl_hist, rcap.data(), (size_t)nl_hist * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            std::vector<int> rc0((size_t)3 * nl_hist);
+            for (int sgi = 0; sgi < nl_hist; ++sgi) {
+                rc0[(size_t)sgi] = tab[sgi].rank_col0;
+                rc0[(size_t)nl_hist + sgi] = tab[sgi].rank_cap;
+                rc0[(size_t)2 * nl_hist + sgi] = first_bin[(size_t)sgi];
+            }
+            HSD_TMP_ALLOC(ctx, dr, rc0.size() * sizeof(int));
+            HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), rc0.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)nl_hist);
-            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, (uint32_t *)ctx->d_X);
-            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, (uint32_t *)ctx->d_X);
+            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, (uint32_t *)ctx->d_X);
+            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, (uint32_t *)ctx->d_X);
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
         }
     }
     if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {
         ctx->list_cap = 1;
-        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + 7) / 8 + 1;
+        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].low_words + tab[s].hi_words + 7) / 8 + 2;
     }
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
     HSD_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tab, tab, (size_t)nsg * sizeof(HsdSegDesc), hipMemcpyHostToDevice, ctx->stream));

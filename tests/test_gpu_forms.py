@@ -1,7 +1,7 @@
 """GPU: alternative evaluation forms of the zero-pad distance give identical results.
 
-* rank form vs bin form of a layer (csrc/pair.hip, SegDesc): the same integer sum, so matrices must be
-  BIT-identical with the rank form disabled (HSD_RANK=0), for packed uint16 and plain uint32 operands, both tile
+* rank form vs bin form of a layer, whole or above a threshold (csrc/pair.hip, SegDesc): the same integer sum, so matrices
+  must be BIT-identical with the rank form disabled (HSD_RANK=0) or restricted to whole layers (HSD_RANK=1), for packed uint16 and plain uint32 operands, both tile
   shapes, aligned and unaligned row ranges, and against the oracle;
 * the fp64 fallback kernel (PAIR_ZP_F64) that serves non-integral supports -- reachable through
   hsd_signature_build with fractional node values -- against the oracle on the raw samples;
@@ -48,11 +48,13 @@ def test_rank_form_bit_identical_to_bin_form(engine, n, pack):
     engine.set_graph(g.rowptr, g.col)
     engine.signature_build_degree(3)
     mats = {}
-    for rank in (1, 0):
+    for rank in (2, 1, 0):                # 2: thresholded (low bins + rank tail), 1: pure rank form only, 0: bin form only
         for tile in (64, 128):
             with _Env(HSD_RANK=rank, HSD_SAD16=pack, HSD_TILE=tile):
                 engine.pair_prepare(0, 1, 0, 2)
                 mats[(rank, tile)] = engine.pair_rows_host()
+                if rank == 2 and tile == 128:
+                    work_thr = engine.pair_work()
                 if rank == 1 and tile == 128:
                     work_rank = engine.pair_work()
                     cols, _ = engine.pair_operand_dims()
@@ -66,6 +68,7 @@ def test_rank_form_bit_identical_to_bin_form(engine, n, pack):
         assert np.array_equal(m, ref), key
     # the rank form was really taken: ring 1 of a scale-free graph has ~10 members against >100 degree bins
     assert work_rank < 0.8 * work_bin, (work_rank, work_bin)
+    assert work_thr <= work_rank, (work_thr, work_rank)
     rs = corc.RingSamples(g.rowptr, g.col, 3, g.degree.astype(np.float64))
     want, _ = rs.pair_rows(0, 2, corc.ALIGN_ZEROPAD, 0, 48)
     assert np.allclose(ref[:48], want, rtol=RTOL, atol=ATOL), np.abs(ref[:48] - want).max()
