@@ -669,6 +669,8 @@ def main():
     cpu_pool = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and wass:
         cpu = {primary_v: scipy_baseline(g, spec["hop"], primary_v, args.cpu_seconds)}
+        for v in variants[1:]:                         # the other variant: a shorter sample, mainly for its parity check
+            cpu[v] = scipy_baseline(g, spec["hop"], v, args.cpu_seconds / 3)
         cpu_pool = scipy_pool_baseline(g, spec["hop"], primary_v, min(10.0, args.cpu_seconds), cpu[primary_v]["rate"])
 
     # HSD_COMM_DRYRUN=1 rehearses the multi-rank flow on a box with fewer GPUs than ranks: every rank on GPU 0,
@@ -712,6 +714,8 @@ def main():
         sec = None
         if len(variants) > 1:
             sec = variant_summary(r["variants"][variants[1]])
+            if cpu and variants[1] in cpu and "error" not in sec:
+                sec["cpu_baseline"] = cpu_entry(cpu[variants[1]], variants[1], spec["hop"], "the same matrix")
         line = {
             "metric": "node-pairs/sec on NxN structural-distance matrix",
             "value": prim["pairs_per_s"], "unit": "node-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

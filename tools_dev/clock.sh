@@ -6,7 +6,7 @@ sets=(); while [ "$1" != "--" ] && [ $# -gt 0 ]; do sets+=("$1"); shift; done; s
 i=0
 for e in "${sets[@]}"; do
   i=$((i+1)); out=$R/gpurun_out/clk_$i; rm -rf $out; mkdir -p $out
-  (cd /tmp && env $e rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out --output-format csv -- python3 $R/bench.py --cpu-seconds 0 --steps 10 --warmup 2 "$@" > $out/log.txt 2>&1)
+  (cd /tmp && env $e rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out --output-format csv -- python3 $R/bench.py --cpu-seconds 0 --configs none --steps 10 --warmup 2 "$@" > $out/log.txt 2>&1)
   echo "== $e"
   python3 - $out <<'PY'
 import csv, glob, sys, collections

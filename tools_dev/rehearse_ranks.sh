@@ -6,4 +6,4 @@
 # spawn further GPU programs on this pool.)
 P=${1:-2}
 HSD_COMM_DRYRUN=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
-    --master-port 29511 bench.py --gpus $P --steps 20 --warmup 3
+    --master-port 29511 bench.py --gpus $P --steps 20 --warmup 3 --workload config2
