@@ -31,10 +31,10 @@ constexpr int HSD_CHUNK = 16;      // columns staged per LDS pass
 constexpr int HSD_MAX_LAYERS = 32;
 constexpr int HSD_LCHUNK = 64;     // CSR entries per chunk of a long Laplacian row
 
-// One layer of a zero-pad distance (csrc/pair.hip, SegDesc): the value axis is cut at a threshold theta.  Below it the
-// layer is always evaluated in bin form (low_*); above it either in bin form (hi_*) or -- when the nodes of a tile pair
-// have few members above theta -- in rank form (rank_*: at most rank_cap words; rank_col0 < 0: none stored).
-struct HsdSegDesc { int low_col0, low_words, hi_col0, hi_words, rank_col0, rank_cap; };
+// One layer of a zero-pad distance (csrc/pair.hip, SegDesc): its bin-form columns [bin_col0, +bin_words), and -- where
+// it pays -- a second column range [rank_col0, ...) holding a copy of the bin columns below the layer's threshold
+// (rank_low words) followed by the rank columns of the members above it (at most rank_cap words).  rank_col0 < 0: none.
+struct HsdSegDesc { int bin_col0, bin_words, rank_col0, rank_low, rank_cap; };
 
 struct hsd_ctx {
     int device = 0;

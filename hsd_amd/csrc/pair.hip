@@ -213,8 +213,9 @@ __device__ inline void store2_full(gdouble *p, double v0, double v1, bool nt) {
 //   bin form   one column per support bin (tail count x bin width), two uint16 columns per word
 //   rank form  one column per rank r: (r-th largest member value - theta)+, zeros beyond the members above theta
 //              -> ceil(R / 2) words, R = most members above theta among the nodes of the two tiles
-// A layer is stored as: bin columns below theta (always evaluated), bin columns above theta, and rank columns above theta; a
-// tile pair takes whichever of the last two is shorter.  theta = 0 is the pure rank form (ring 1 of a scale-free graph:
+// A layer is stored as its bin columns (all of them, contiguous) and, in a second range, a copy of the bin columns below
+// theta followed by the rank columns above theta; a tile pair reads whichever range is shorter -- one contiguous run of
+// columns either way.  theta = 0 is the pure rank form (ring 1 of a scale-free graph:
 // ~10 members against 241 degree bins); ring 2 (hundreds of members, a few dozen of them hubs) keeps the dense low bins
 // and takes its sparse tail by rank.  Same integer either way, so the result is bit-identical.
 struct SegDesc : HsdSegDesc {};    // columns in words
@@ -224,12 +225,12 @@ struct SegDesc : HsdSegDesc {};    // columns in words
 // Returns the inclusive prefix of the chunk counts (lane 63: the list length).
 template <int CH, bool PACK>
 __device__ inline int plan_segment(const SegDesc &sd, bool active, uint32_t R, int l, int2 *lst) {
-    int lc = sd.low_col0, lw = active ? sd.low_words : 0, hc = sd.hi_col0, hw = active ? sd.hi_words : 0;
+    int col0 = sd.bin_col0, words = active ? sd.bin_words : 0;
     if (active && sd.rank_col0 >= 0) {
         const int wr = PACK ? (int)((R + 1) >> 1) : (int)R;
-        if (wr <= sd.rank_cap) { hc = sd.rank_col0; hw = wr; }
+        if (wr <= sd.rank_cap) { col0 = sd.rank_col0; words = sd.rank_low + wr; }     // low bins (copy) + ranks: one contiguous range
     }
-    const int nlo = (lw + CH - 1) / CH, nhi = (hw + CH - 1) / CH, nch = nlo + nhi;
+    const int nch = (words + CH - 1) / CH;
     int pre = nch;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -237,10 +238,8 @@ __device__ inline int plan_segment(const SegDesc &sd, bool active, uint32_t R, i
         if (l >= o) pre += up;
     }
     int2 *dst = lst + (pre - nch);
-    for (int c = 0; c < nlo; ++c)
-        dst[c] = make_int2(lc + c * CH, min(CH, lw - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
-    for (int c = 0; c < nhi; ++c)
-        dst[nlo + c] = make_int2(hc + c * CH, min(CH, hw - c * CH) | ((nlo + c == nch - 1) ? 0x100 : 0) | (l << 16));
+    for (int c = 0; c < nch; ++c)
+        dst[c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
     return pre;
 }
 
@@ -630,6 +629,8 @@ __device__ inline void wait_vm_young(int young) {
     if (young >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
     else if (young >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (young >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (young >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (young >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -641,7 +642,6 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     constexpr bool SEG = (KIND == K_SAD || KIND == K_ZP || KIND == K_SAD16);
     constexpr int CH = stream_chunk_cols(KIND, NW);
     constexpr int STAGE = 2 * CH * BT;               // elements per stage: I block, then J block
-    constexpr int LOADS = 2 * CH * BT * (int)sizeof(T) / 1024 / NW;   // 1-KiB direct-to-LDS instructions per chunk and wave
     static_assert(NW == 1 || NW == 4, "one wave (64 x 64 tile) or four (128 x 128)");
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     T *sbase = reinterpret_cast<T *>(lds_raw);
@@ -688,27 +688,30 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         if (l < a.n_seg) sd = a.seg_tab[l];
         else sd.rank_col0 = -1;
     }
-    auto stage_chunk = [&](int col, int64_t ri0, int64_t rj0, int st) __attribute__((always_inline)) {
-        // LOADS / 2 instructions per side and wave, each 64 lanes x 16 B = COLS columns x (BT nodes x sizeof(T)) bytes
+    // requests the first `valid` columns of a chunk (the tail of a layer's last chunk is not fetched); returns the number of
+    // direct-to-LDS instructions THIS wave issued
+    auto stage_chunk = [&](int col, int valid, int64_t ri0, int64_t rj0, int st) __attribute__((always_inline)) -> int {
+        // up to LOADS / 2 instructions per side and wave, each 64 lanes x 16 B = COLS columns x (BT nodes x sizeof(T)) bytes
         constexpr int LANES_PER_COL = BT * (int)sizeof(T) / 16;
         constexpr int COLS = 64 / LANES_PER_COL;
         static_assert((CH / COLS) % NW == 0, "stage instructions must divide over the waves");
         asm volatile("" ::: "memory");               // no load / store moves across the request: vm_seq below relies on the order
         const uint32_t dst_lds = lds_base + (uint32_t)(st * STAGE * sizeof(T));
         const uint32_t lane_off = (uint32_t)(l / LANES_PER_COL) * (uint32_t)(a.npad * sizeof(T)) + 16u * (l % LANES_PER_COL);
+        int issued = 0;
 #pragma unroll
         for (int k = 0; k < CH / COLS / NW; ++k) {
             const int ins = k * NW + w;
-            glds16_s(reinterpret_cast<uint64_t>(XI + (int64_t)(col + ins * COLS) * a.npad + ri0), lane_off,
-                     dst_lds + (uint32_t)(ins * COLS * BT * sizeof(T)));
-        }
-#pragma unroll
-        for (int k = 0; k < CH / COLS / NW; ++k) {
-            const int ins = k * NW + w;
-            glds16_s(reinterpret_cast<uint64_t>(XJ + (int64_t)(col + ins * COLS) * a.npad + rj0), lane_off,
-                     dst_lds + (uint32_t)((CH * BT + ins * COLS * BT) * sizeof(T)));
+            if (ins * COLS < valid) {
+                glds16_s(reinterpret_cast<uint64_t>(XI + (int64_t)(col + ins * COLS) * a.npad + ri0), lane_off,
+                         dst_lds + (uint32_t)(ins * COLS * BT * sizeof(T)));
+                glds16_s(reinterpret_cast<uint64_t>(XJ + (int64_t)(col + ins * COLS) * a.npad + rj0), lane_off,
+                         dst_lds + (uint32_t)((CH * BT + ins * COLS * BT) * sizeof(T)));
+                issued += 2;
+            }
         }
         asm volatile("" ::: "memory");
+        return issued;
     };
     // one 1-KiB instruction per vector and side (128 doubles; a 64-node tile uses the first half), dealt over the waves;
     // issued in front of the tile's first chunk, so the wait for that chunk covers them
@@ -755,6 +758,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         if constexpr (SEG) return __builtin_amdgcn_readfirstlane(clist[buf * a.list_cap + k].x);
         else return k * CH;
     };
+    auto chunk_valid = [&](int buf, int k) __attribute__((always_inline)) -> int {
+        if constexpr (SEG) return __builtin_amdgcn_readfirstlane(clist[buf * a.list_cap + k].y) & 0xff;
+        else return min(CH, a.dcols_valid - k * CH);
+    };
 
     // ---- prologue: plan of the first tile, coordinates of the next two ----
     int ti, tj;
@@ -780,8 +787,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     int st = 0;                                       // LDS stage of the next chunk to be computed
     int ahead = 0;                                    // chunks of the current tile whose loads are already issued
     vm_seq += stage_aux(i0, j0, cur);
-    if (n0 > 0) { stage_chunk(chunk_col(cur, 0), i0, j0, 0); vm_seq += LOADS; seq_of_stage[0] = vm_seq; ahead = 1; }
-    if (n0 > 1) { stage_chunk(chunk_col(cur, 1), i0, j0, 1); vm_seq += LOADS; seq_of_stage[1] = vm_seq; ahead = 2; }
+    if (n0 > 0) { vm_seq += stage_chunk(chunk_col(cur, 0), chunk_valid(cur, 0), i0, j0, 0); seq_of_stage[0] = vm_seq; ahead = 1; }
+    if (n0 > 1) { vm_seq += stage_chunk(chunk_col(cur, 1), chunk_valid(cur, 1), i0, j0, 1); seq_of_stage[1] = vm_seq; ahead = 2; }
     unsigned long long work = 0;
     bool first_landed = false;
 
@@ -837,14 +844,14 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             if (k >= 1 || ahead < 2) {
                 // (k == 0 with two chunks in flight: nothing to request, both stages are taken)
                 if (ahead < n0) {
-                    stage_chunk(chunk_col(cur, ahead), i0, j0, st ^ 1);
-                    vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ++ahead;
+                    vm_seq += stage_chunk(chunk_col(cur, ahead), chunk_valid(cur, ahead), i0, j0, st ^ 1);
+                    seq_of_stage[st ^ 1] = vm_seq; ++ahead;
                 } else if (has1 && !aux1) {
                     vm_seq += stage_aux(i1, j1, cur ^ 1);     // the next tile's vectors, then its first chunk
                     aux1 = true;
                     if (n1 > 0) {
-                        stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st ^ 1);
-                        vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 1;
+                        vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), i1, j1, st ^ 1);
+                        seq_of_stage[st ^ 1] = vm_seq; ahead1 = 1;
                     }
                 }
             }
@@ -946,12 +953,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         wg_barrier();                                 // the stage of the last chunk is free only when every wave has consumed it
         if (has1 && !aux1) { vm_seq += stage_aux(i1, j1, cur ^ 1); aux1 = true; }
         if (ahead1 == 0 && n1 > 0) {
-            stage_chunk(chunk_col(cur ^ 1, 0), i1, j1, st);
-            vm_seq += LOADS; seq_of_stage[st] = vm_seq; ahead1 = 1;
+            vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), i1, j1, st);
+            seq_of_stage[st] = vm_seq; ahead1 = 1;
         }
         if (ahead1 == 1 && n1 > 1) {
-            stage_chunk(chunk_col(cur ^ 1, 1), i1, j1, st ^ 1);
-            vm_seq += LOADS; seq_of_stage[st ^ 1] = vm_seq; ahead1 = 2;
+            vm_seq += stage_chunk(chunk_col(cur ^ 1, 1), chunk_valid(cur ^ 1, 1), i1, j1, st ^ 1);
+            seq_of_stage[st ^ 1] = vm_seq; ahead1 = 2;
         }
         // A wave can have 63 vector-memory operations outstanding at most, and they retire in order: a wait for operand
         // loads issued BEFORE this tile's 128 stores still needs about half of those stores acknowledged.  So the next
@@ -1649,7 +1656,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `two` leaves scope
     }
     HsdSegDesc *tab = ctx->seg_tab;
-    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{0, 0, s * stride, B, -1, 0};
+    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0, 0};
     ctx->dcols_alg = nl_hist * B;
 
     if (!use_u32 || nl_hist == 0) {
@@ -1744,7 +1751,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         std::vector<uint32_t> rmax_sel((size_t)nl_hist * ngran, 0u);
         const int64_t G = (n + 63) / 64;
         for (int sgi = 0; sgi < nl_hist; ++sgi) {
-            tab[sgi] = HsdSegDesc{0, 0, sgi * bin_stride, bin_words, -1, 0};      // everything in the "upper" bin part
+            tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0, 0};
             list_cap += (bin_words + 7) / 8 + 2;        // either kernel: chunks of 32 / 16 words (uint32) or 16 / 8 columns (fp64)
             if (!rank_ok || bin_words < 2) continue;
             double best_cost = 0.97 * bin_words;
@@ -1768,16 +1775,13 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             }
             if (best_q < 0) continue;
             const int low_w = vfirst[(size_t)cand[(size_t)best_q]] / (pack ? 2 : 1);
-            tab[sgi].low_col0 = sgi * bin_stride;
-            tab[sgi].low_words = low_w;
-            tab[sgi].hi_col0 = sgi * bin_stride + low_w;
-            tab[sgi].hi_words = bin_words - low_w;
             tab[sgi].rank_col0 = col;
+            tab[sgi].rank_low = low_w;
             tab[sgi].rank_cap = best_cap;
             first_bin[(size_t)sgi] = cand[(size_t)best_q];
             std::copy(gmax.data() + ((size_t)sgi * NC + best_q) * ngran, gmax.data() + ((size_t)sgi * NC + best_q + 1) * ngran,
                       rmax_sel.begin() + (size_t)sgi * ngran);
-            col += (int)round_up(best_cap, CH);
+            col += (int)round_up(low_w + best_cap, CH);
         }
         HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax, rmax_sel.data(), rmax_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // rmax_sel is a local
@@ -1814,9 +1818,12 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             DevTmp dr;
             std::vector<int> rc0((size_t)3 * nl_hist);
             for (int sgi = 0; sgi < nl_hist; ++sgi) {
-                rc0[(size_t)sgi] = tab[sgi].rank_col0;
+                rc0[(size_t)sgi] = tab[sgi].rank_col0 < 0 ? -1 : tab[sgi].rank_col0 + tab[sgi].rank_low;
                 rc0[(size_t)nl_hist + sgi] = tab[sgi].rank_cap;
                 rc0[(size_t)2 * nl_hist + sgi] = first_bin[(size_t)sgi];
+                if (tab[sgi].rank_col0 >= 0 && tab[sgi].rank_low > 0)       // the bin columns below the threshold, once more in front of the ranks
+                    HSD_HIP(ctx, hipMemcpyAsync((uint32_t *)ctx->d_X + (size_t)tab[sgi].rank_col0 * npad, (uint32_t *)ctx->d_X + (size_t)tab[sgi].bin_col0 * npad,
+                                                (size_t)tab[sgi].rank_low * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
             }
             HSD_TMP_ALLOC(ctx, dr, rc0.size() * sizeof(int));
             HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), rc0.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -1828,7 +1835,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     }
     if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {
         ctx->list_cap = 1;
-        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].low_words + tab[s].hi_words + 7) / 8 + 2;
+        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + 7) / 8 + 2;
     }
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
     HSD_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tab, tab, (size_t)nsg * sizeof(HsdSegDesc), hipMemcpyHostToDevice, ctx->stream));
