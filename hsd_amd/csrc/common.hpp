@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hsd.h"
@@ -111,6 +112,9 @@ struct hsd_ctx {
     ncclComm *comm = nullptr;
     int world = 1, rank = 0;
     int64_t rows_per_rank = 0;
+
+    // dynamic-LDS limit already raised for a kernel on this context's device (kernel address -> bytes)
+    std::unordered_map<const void *, size_t> lds_attr;
 
     // cached explicit tile orders of the pair kernel (device int2 arrays)
     struct TileList { int tiles_i, tiles_j, sym, group; void *d; int count; };

@@ -151,7 +151,9 @@ __device__ inline void glds16(const void *g, void *lds_wave_base) {
 // (Inside the persistent kernel hipcc re-associates base + offset and keeps one 64-bit VECTOR address per instruction
 // live across the tile loop -- 16 register pairs, spilled to scratch and reloaded behind s_waitcnt vmcnt(0).)
 __device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory", "m0");
+    // (M0 is a reserved register: hipcc does not accept it as a clobber.  Nothing else in pair_stream_kernel uses M0 -- DS
+    // instructions do not on gfx9+, and the kernel contains no LDS-DMA builtin, s_movrel or message instruction.)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
 }
 
 // Stage CH columns x BT nodes of one operand: LDS image [CH][BT] of T (linear, as in memory).
@@ -1228,13 +1230,13 @@ hipError_t launch_pair(hsd_ctx *ctx, const PairArgs &a, int grid, hipStream_t st
     auto kern = pair_kernel<KIND, FAST, TR>;
     // 2 stages x (I, J) operand chunks, then (segmented kinds) the tile's chunk list + its length
     const size_t lds = (size_t)2 * 2 * chunk_cols(KIND) * (16 * TR) * sizeof(typename Elem<KIND>::type) + (size_t)a.list_cap * sizeof(int2) + 16;
-    static size_t attr_lds = 0;
+    // the attribute is per device: remembered per context (one context per GPU), not per process
+    size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_lds = lds;
     }
-    (void)ctx;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, a);
     return hipGetLastError();
 }
@@ -1321,7 +1323,8 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     constexpr int BT = NW == 4 ? 128 : 64;
     const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 +
                        (size_t)2 * a.n_aux * 256 * sizeof(double);
-    static size_t attr_lds = 0;
+    // the attribute is per device: remembered per context (one context per GPU), not per process
+    size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1329,11 +1332,8 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     }
     // persistent grid: two waves per SIMD on every CU (HSD_WAVES_PER_CU overrides), a multiple of 8 so that every XCD
     // gets the same number of workgroups; a workgroup with no tile in its XCD's run exits at once
-    static int per_cu = 0;
-    if (!per_cu) {
-        const char *e = getenv("HSD_WAVES_PER_CU");
-        per_cu = e ? std::max(NW, atoi(e)) : 8;
-    }
+    const char *ew = getenv("HSD_WAVES_PER_CU");
+    const int per_cu = ew ? std::max(NW, atoi(ew)) : 8;
     const int64_t resident = (int64_t)(per_cu / NW) * ctx->prop.multiProcessorCount / 8 * 8;
     const int grid = (int)std::min<int64_t>(resident, round_up(a.ntiles, 8));
     {
