@@ -1407,6 +1407,12 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     const int nw = stream_waves(ctx, a);
     if (nw) BT = nw == 4 ? 128 : 64;
+    else if (BT == 128 && !getenv("HSD_TILE") && ctx->mode != PAIR_ZP_F64) {
+        // few tiles per CU: the small tile's five workgroups per CU overlap their phases better than two large ones
+        // (ER N = 10k, raw fp64 W1: 0.321 ms with 64 x 64 tiles against 0.351 ms with 128 x 128)
+        const int64_t t128i = (a.i_end - a.i_begin + 127) / 128, t128j = (a.j_end - a.j_begin + 127) / 128;
+        if ((a.sym ? t128i * (t128i + 1) / 2 : t128i * t128j) < 16 * (int64_t)ctx->prop.multiProcessorCount) BT = 64;
+    }
     a.tiles_i = (int)((a.i_end - a.i_begin + BT - 1) / BT);
     a.tiles_j = (int)((a.j_end - a.j_begin + BT - 1) / BT);
     if (a.tiles_i <= 0 || a.tiles_j <= 0) return HSD_OK;
