@@ -1003,7 +1003,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
         } else {
-            gdouble *pd = out + (i0 + wi - a.rbase) * a.ld + (j0 + wj);
+            // HSD_DEBUG bit 4 (measurement): every tile stores into the first tile's place -- the same store instructions
+            // without the HBM write stream (the lines stay in L2)
+            const int64_t si0 = (a.dbg & 16) ? a.i_begin : i0, sj0 = (a.dbg & 16) ? a.j_begin + BT : j0;
+            gdouble *pd = out + (si0 + wi - a.rbase) * a.ld + (sj0 + wj);
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 gdouble *row = pd + (int64_t)(16 * (r >> 1) + (r & 1)) * a.ld;
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             vm_seq += TR * TC / 2;
             if (a.mirror) {
-                gdouble *pm = out + (j0 + wj - a.rbase) * a.ld + (i0 + wi);
+                gdouble *pm = out + (sj0 + wj - a.rbase) * a.ld + (si0 + wi);
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
                     gdouble *row = pm + (int64_t)(16 * (cc >> 1) + (cc & 1)) * a.ld;
