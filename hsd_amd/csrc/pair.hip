@@ -793,6 +793,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     if (n0 > 1) { vm_seq += stage_chunk(chunk_col(cur, 1), chunk_valid(cur, 1), i0, j0, 1); seq_of_stage[1] = vm_seq; ahead = 2; }
     unsigned long long work = 0;
     bool first_landed = false;
+    unsigned long long cyc_store = 0, cyc_loop = 0, cyc_epi = 0, n_tiles = 0;      // HSD_DEBUG bit 3 only
 
     while (true) {
         double acc[TR][TC];
@@ -821,6 +822,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         int ahead1 = 0;                               // chunks of the NEXT tile already requested
         bool aux1 = false;                            // ... and its auxiliary vectors
 
+        const unsigned long long c_l0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int k = 0; k < n0; ++k) {
             int cvalid, seg = 0;
             bool ends_seg = false;
@@ -935,6 +937,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             st ^= 1;
         }
+        const unsigned long long c_l1 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
         // the second chunk of the next tile goes out BEFORE this tile's stores: its loads then do not queue behind them
         if (w == 0 && l == 0) {
             // position of the drawn tile in the order, or -1 when every run is exhausted.  A workgroup whose own XCD's run
@@ -1000,6 +1003,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         }
         // ---- stores ----
         asm volatile("" ::: "memory");
+        const unsigned long long c_s0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
         if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
         } else {
@@ -1026,6 +1030,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
         }
         // (edge and diagonal tiles are not in this kernel's list: the one-tile kernel stores them with per-element masks)
+        if (a.dbg & 8) {
+            asm volatile("" ::: "memory");
+            const unsigned long long c_s1 = __builtin_amdgcn_s_memtime();
+            cyc_loop += c_l1 - c_l0; cyc_epi += c_s0 - c_l1; cyc_store += c_s1 - c_s0; ++n_tiles;
+        }
         if (!has1) break;
         // ---- rotate: next tile becomes current ----
         i0 = i1; j0 = j1; i1 = i2; j1 = j2;
@@ -1038,9 +1047,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     if (a.work && threadIdx.x == 0) atomicAdd(a.work, work * (unsigned long long)(BT * BT));
     if ((a.dbg & 8) && a.cand_val && threadIdx.x == 0) {
         // measurement hook: (start, end) of this workgroup in 100 MHz ticks, in a buffer nothing else reads
-        unsigned long long *st = reinterpret_cast<unsigned long long *>(a.cand_val) + 2 * (size_t)blockIdx.x;
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(a.cand_val) + 6 * (size_t)blockIdx.x;
         st[0] = stamp0;
         st[1] = __builtin_amdgcn_s_memrealtime();
+        st[2] = cyc_loop; st[3] = cyc_epi; st[4] = cyc_store; st[5] = n_tiles;
     }
 }
 
@@ -1347,13 +1357,14 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
         // HSD_DEBUG bit 3: per-workgroup lifetimes -> stderr (synchronises; measurement only)
         PairArgs b = a;
         unsigned long long *d_st = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&d_st), (size_t)grid * 16) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemset(d_st, 0, (size_t)grid * 16);
+        if (hipMalloc(reinterpret_cast<void **>(&d_st), (size_t)grid * 48) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d_st, 0, (size_t)grid * 48);
         b.cand_val = reinterpret_cast<double *>(d_st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, b);
         (void)hipStreamSynchronize(stream);
-        std::vector<unsigned long long> h((size_t)grid * 2);
-        (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h6((size_t)grid * 6), h((size_t)grid * 2);
+        (void)hipMemcpy(h6.data(), d_st, h6.size() * 8, hipMemcpyDeviceToHost);
+        for (int g = 0; g < grid; ++g) { h[2 * g] = h6[6 * g]; h[2 * g + 1] = h6[6 * g + 1]; }
         (void)hipFree(d_st);
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int g = 0; g < grid; ++g) if (h[2 * g]) { t0 = std::min(t0, h[2 * g]); t1 = std::max(t1, h[2 * g + 1]); }
@@ -1366,6 +1377,9 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
         fprintf(stderr, "[hsd stream<%d,%d>] %zu workgroups, span %.1f us; end times us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f; mean end per b%%8:", KIND, NW,
                 endt.size(), (t1 - t0) * 1e-2, endt.front(), endt[endt.size() / 10], endt[endt.size() / 2], endt[endt.size() * 9 / 10], endt.back());
         for (int x8 = 0; x8 < 8; ++x8) fprintf(stderr, " %.0f", cnt[x8] ? per_xcd[x8] / cnt[x8] : 0.0);
+        double cl = 0, ce = 0, cs = 0, nt = 0;
+        for (int g = 0; g < grid; ++g) { cl += (double)h6[6 * g + 2]; ce += (double)h6[6 * g + 3]; cs += (double)h6[6 * g + 4]; nt += (double)h6[6 * g + 5]; }
+        if (nt > 0) fprintf(stderr, "; wave-0 cycles per tile: chunk loop %.0f, fold + next-tile requests %.0f, stores %.0f (%.0f tiles)", cl / nt, ce / nt, cs / nt, nt);
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
