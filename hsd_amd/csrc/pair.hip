@@ -608,8 +608,11 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
 
 // ------------------------------------------------------------------------------------------
 // pair_stream_kernel<KIND, NW>: the same arithmetic as a PERSISTENT workgroup that streams through its tiles.
-//   NW = 4: 128 x 128 tiles as above (wave w owns quadrant (w >> 1, w & 1)), one barrier per operand chunk;
-//   NW = 1: ONE WAVE per workgroup and NO barriers (64 x 64 tiles).
+//   NW = 4: 128 x 128 tiles as above (wave w owns quadrant (w >> 1, w & 1)), one barrier per operand chunk -- the only
+//           instantiation that is built;
+//   NW = 1: ONE WAVE per workgroup and NO barriers (64 x 64 tiles) -- what the kernel started as (next paragraph); it
+//           stages twice the operand bytes per pair and measured 247 vs 219 ms (raw fp64 W1) / 31 vs 29 ms (zero-pad) at
+//           BA N = 100k, so it is no longer instantiated; the NW == 1 branches are kept as the record of that design.
 //
 // Measured on the 4-wave kernel above at BA N = 100k (profiles/r02a_*): with the zero-pad distance down to ~137 words
 // per pair the waves sat in s_waitcnt / s_barrier for 29 % of their cycles and the vector ALU was busy 62 % of the
