@@ -825,6 +825,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         int ahead1 = 0;                               // chunks of the NEXT tile already requested
         bool aux1 = false;                            // ... and its auxiliary vectors
 
+        if (n0 == 0) {
+            // a tile without operand chunks (no histogram layer compared): nothing below waits for its per-node vectors
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier();
+        }
         const unsigned long long c_l0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int k = 0; k < n0; ++k) {
             int cvalid, seg = 0;

@@ -158,3 +158,24 @@ def test_persistent_kernels_bit_identical(engine, nw):
         # its two halves in the other order)
         assert np.array_equal(blk, ref[1024:2048]) if metric != 2 else np.allclose(blk, ref[1024:2048], rtol=1e-9, atol=1e-15)
         assert work > 0
+
+
+def test_persistent_kernel_corner_shapes(engine):
+    """Forced persistent kernel on shapes its size heuristic would not pick: a distance with NO histogram layer (K = 1,
+    layers 0..0: tiles without operand chunks, only the ring-0 term), and a hierarchy too deep for its LDS budget
+    (K = 4 zero-pad: three layers + ring 0 = four per-node vectors -> every tile falls back to the one-tile kernel)."""
+    g = _scale_free(2600, seed=3)
+    engine.set_graph(g.rowptr, g.col)
+    deg = g.degree.astype(np.float64)
+    engine.signature_build_degree(1)
+    with _Env(HSD_STREAM=1):
+        engine.pair_prepare(0, 1, 0, 0)
+        D0 = engine.pair_rows_host()
+    assert np.array_equal(D0, np.abs(deg[:, None] - deg[None, :]))
+    engine.signature_build_degree(4)
+    out = {}
+    for stream in (0, 1):
+        with _Env(HSD_STREAM=stream):
+            engine.pair_prepare(0, 1, 0, 3)
+            out[stream] = engine.pair_rows_host()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[0].T)
