@@ -57,11 +57,23 @@ struct hsd_ctx {
     int32_t *d_queue = nullptr;
     int64_t queue_blocks = 0;
 
+    // bit-parallel k-hop sweep (khop_ms.hip): plane scratch and the chunk lists of long adjacency rows
+    unsigned long long *d_ms_planes = nullptr;
+    size_t ms_plane_words = 0;
+    int32_t *d_ms_row_first = nullptr;   // [n] first chunk of the row, or -1
+    int32_t *d_ms_chunk_row = nullptr;
+    int64_t *d_ms_chunk_p0 = nullptr;
+    int ms_n_chunks = 0;
+    bool ms_chunks_ready = false;
+    hipStream_t ms_stream = nullptr;     // histogram pass of batch b beside the pulls of batch b + 1
+    hipEvent_t ms_ev_rings[2] = {nullptr, nullptr}, ms_ev_hist[2] = {nullptr, nullptr};
+
     // signature (counts resident on device)
     int hop = -1, n_bins = 0;
     int64_t n_rows_alloc = 0;          // rows allocated (n rounded up to world * rows_per_rank)
     uint32_t *d_counts = nullptr;      // [n_rows_alloc][hop+1][n_bins]
     int32_t *d_node_bin = nullptr;     // [n]
+    std::vector<int32_t> h_node_bin;   // host copy of what d_node_bin holds
     double *d_support = nullptr;       // [n_bins]
     std::vector<double> support;
     bool support_integral = false;
@@ -164,9 +176,22 @@ static inline void hsd_dev_free(T *&p) {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// dynamic-LDS limit of a kernel, raised once per context (the attribute is per device)
+static inline int hsd_raise_lds_limit(hsd_ctx *ctx, const void *kern, size_t bytes) {
+    size_t &have = ctx->lds_attr[kern];
+    if (bytes > have) {
+        HSD_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return HSD_OK;
+}
+
 // implemented in the per-kernel translation units
 int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, int32_t *d_sizes,
                     const int64_t *d_offsets, int32_t *d_members);
+int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1);
+bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop);
+void hsd_khop_ms_release(hsd_ctx *ctx);
 void hsd_release_operands(hsd_ctx *ctx);
 extern "C" void hsd_heat_release_internal(hsd_ctx *ctx);
 int hsd_launch_pair_rowquirk_tiled(hsd_ctx *ctx, const double *psi_dev, int64_t ldpsi, int64_t r0, int64_t r1, double *dst, int64_t dld);

@@ -84,6 +84,7 @@ extern "C" void hsd_destroy(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_rowptr);
     hsd_dev_free(ctx->d_col);
     hsd_dev_free(ctx->d_queue);
+    hsd_khop_ms_release(ctx);
     hsd_dev_free(ctx->d_counts);
     hsd_dev_free(ctx->d_node_bin);
     hsd_dev_free(ctx->d_support);
@@ -98,6 +99,12 @@ extern "C" void hsd_destroy(hsd_ctx *ctx) {
         if (ctx->side[t]) (void)hipStreamDestroy(ctx->side[t]);
         if (ctx->ev_join[t]) (void)hipEventDestroy(ctx->ev_join[t]);
     }
+    if (ctx->ms_stream) (void)hipStreamSynchronize(ctx->ms_stream);
+    for (int t = 0; t < 2; ++t) {
+        if (ctx->ms_ev_rings[t]) (void)hipEventDestroy(ctx->ms_ev_rings[t]);
+        if (ctx->ms_ev_hist[t]) (void)hipEventDestroy(ctx->ms_ev_hist[t]);
+    }
+    if (ctx->ms_stream) (void)hipStreamDestroy(ctx->ms_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -196,8 +203,10 @@ extern "C" int hsd_set_graph(hsd_ctx *ctx, int64_t n, const int64_t *rowptr, con
     hsd_dev_free(ctx->d_rowptr);
     hsd_dev_free(ctx->d_col);
     hsd_dev_free(ctx->d_queue);
+    hsd_khop_ms_release(ctx);
     hsd_dev_free(ctx->d_counts);
     hsd_dev_free(ctx->d_node_bin);
+    ctx->h_node_bin.clear();
     hsd_dev_free(ctx->d_support);
     hsd_release_operands(ctx);
     hsd_heat_release_internal(ctx);

@@ -170,6 +170,12 @@ hipError_t launch_g(hsd_ctx *ctx, int grid, size_t lds_bytes, int hop, int64_t r
 int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, int32_t *d_sizes, const int64_t *d_offsets,
                     int32_t *d_members) {
     const int64_t n = ctx->n;
+    // histograms only: the bit-parallel sweep of 4096 sources at a time (khop_ms.hip) once the graph is large enough to
+    // fill its planes; HSD_KHOP_MS=0 / 1 forces the per-source sweep / the bit-parallel one
+    if (hist && !d_sizes && !d_members && hsd_khop_ms_usable(ctx, hop)) {
+        const char *em = getenv("HSD_KHOP_MS");
+        if (em ? atoi(em) != 0 : (n >= 8192 && hop >= 2)) return hsd_launch_khop_ms(ctx, hop, r0, r1);
+    }
     const int words = (int)((n + 31) / 32);
     const int n_hist = hist ? (hop + 1) * ctx->n_bins : 0;
     const size_t lds_cap = ctx->prop.maxSharedMemoryPerMultiProcessor ? ctx->prop.maxSharedMemoryPerMultiProcessor : 65536;

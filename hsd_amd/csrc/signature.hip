@@ -40,13 +40,23 @@ extern "C" int hsd_signature_build(hsd_ctx *ctx, int hop, const int32_t *node_bi
     } else {
         hsd_release_operands(ctx);
     }
-    hsd_dev_free(ctx->d_node_bin);
-    hsd_dev_free(ctx->d_support);
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_node_bin, (size_t)ctx->n))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_support, (size_t)n_bins))) return rc;
-    HSD_HIP(ctx, hipMemcpyAsync(ctx->d_node_bin, node_bin, (size_t)ctx->n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HSD_HIP(ctx, hipMemcpyAsync(ctx->d_support, support, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the bin of every node and the support stay on the device between builds over the same values (row blocks
+    // built in turn, repeated builds): only a change is uploaded
+    const bool same_bins = ctx->d_node_bin && ctx->d_support && ctx->h_node_bin.size() == (size_t)ctx->n &&
+                           ctx->support.size() == (size_t)n_bins && std::equal(node_bin, node_bin + ctx->n, ctx->h_node_bin.begin()) &&
+                           std::equal(support, support + n_bins, ctx->support.begin());
+    if (!same_bins) {
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hsd_dev_free(ctx->d_node_bin);
+        hsd_dev_free(ctx->d_support);
+        ctx->h_node_bin.clear();
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_node_bin, (size_t)ctx->n))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_support, (size_t)n_bins))) return rc;
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_node_bin, node_bin, (size_t)ctx->n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_support, support, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->h_node_bin.assign(node_bin, node_bin + ctx->n);
+    }
     ctx->support.assign(support, support + n_bins);
     ctx->support_integral = true;
     for (int b = 0; b < n_bins; ++b)
@@ -61,13 +71,19 @@ extern "C" int hsd_signature_build(hsd_ctx *ctx, int hop, const int32_t *node_bi
 extern "C" int hsd_signature_build_degree(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "no graph uploaded");
-    std::vector<int32_t> uniq(ctx->h_degree);
-    std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    std::vector<double> support(uniq.begin(), uniq.end());
+    // distinct degrees in ascending order = the support; a node's bin is the rank of its degree
+    int32_t dmax = 0;
+    for (int32_t d : ctx->h_degree) dmax = std::max(dmax, d);
+    std::vector<int32_t> rank((size_t)dmax + 1, 0);
+    for (int32_t d : ctx->h_degree) rank[(size_t)d] = 1;
+    std::vector<double> support;
+    for (int32_t d = 0; d <= dmax; ++d)
+        if (rank[(size_t)d]) {
+            rank[(size_t)d] = (int32_t)support.size();
+            support.push_back((double)d);
+        }
     std::vector<int32_t> bin((size_t)ctx->n);
-    for (int64_t i = 0; i < ctx->n; ++i)
-        bin[(size_t)i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), ctx->h_degree[(size_t)i]) - uniq.begin());
+    for (int64_t i = 0; i < ctx->n; ++i) bin[(size_t)i] = rank[(size_t)ctx->h_degree[(size_t)i]];
     return hsd_signature_build(ctx, hop, bin.data(), (int)support.size(), support.data(), r0, r1);
 }
 
