@@ -370,10 +370,18 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
         sizes = eng.khop_sizes(hop, r0, min(r1, r0 + 2000))                # sample of sources for the ball sizes
         inner = float(sizes[:, :hop].sum(axis=1).mean())                   # |ball_{K-1}| per source
         bytes_sweep = (r1 - r0) * inner * (8.0 + 4.0 * float(g.degree.mean())) + 4.0 * (r1 - r0) * (hop + 1) * n_bins
-        sweep = {"kernel": "khop_kernel (k-hop sweep + per-hop histograms)", "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
+        bit_parallel = n >= 8192 and hop >= 2 and os.environ.get("HSD_KHOP_MS", "1") != "0"    # the library's own rule (csrc/khop.hip)
+        sweep = {"kernel": ("ms_pull / ms_hist kernels (bit-parallel k-hop sweep, 4096 sources per batch, + per-hop histograms)" if bit_parallel
+                            else "khop_kernel (per-source k-hop sweep + per-hop histograms)"),
+                 "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
                  "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
                  "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "bound": "LDS atomics / latency (the graph is L2-resident), not HBM"}
+                 "bound": ("row gathers out of the Infinity Cache: (hop - 1) * nnz * n / 8 bytes of frontier rows per sweep"
+                           if bit_parallel else "LDS atomics / latency (the graph is L2-resident), not HBM")}
+        if bit_parallel:
+            moved = (hop - 1) * (float(g.rowptr[-1]) + 4.0 * n) * 512.0 * ((r1 - r0 + 4095) // 4096)     # gathered + streamed plane rows
+            sweep["plane_bytes_moved"] = moved
+            sweep["plane_GBps"] = round(moved / (sweep_ms * 1e-3) / 1e9, 1)
     t0 = time.perf_counter()
     hdist.allgather_signature(eng, rk.dist, rk.rank, rk.world, via="host" if dryrun else "rccl")   # ONE ncclAllGather over xGMI
     eng.sync()

@@ -11,7 +11,9 @@
 //   ring k >= 2     : pull.  One wave per vertex i ORs the frontier rows of its neighbours (the neighbour index is
 //                     wave-uniform, every gather is one 512-B row), new = acc & ~V[i].  Rows longer than 2 * HSD_LCHUNK
 //                     entries are ORed chunk-wise by a pre-pass.  A vertex already reached by every source of the batch is
-//                     skipped (the last hops of a small-world graph).  Work per hop is nnz * n / 64 word ORs whatever the
+//                     skipped (the last hops of a small-world graph).  (A flag per frontier row that lets the pull skip empty
+//                     rows -- most rows when the frontier is ring 1 -- was measured: the dependent scalar load in front of
+//                     every gather costs more than the rows it saves, 86 -> 119 us per pull at BA N = 100k.)  Work per hop is nnz * n / 64 word ORs whatever the
 //                     ring sizes, against sum of ring sizes * mean degree single-bit operations of the per-source sweep.
 //   histograms      : one workgroup per (word, hop, vertex share): counts[64 sources][bins] in LDS; blocks of 64 vertices are
 //                     transposed across the wave (lane = source) and counted bin by bin with popcounts, then added to the
@@ -20,6 +22,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -144,16 +147,20 @@ __device__ inline unsigned long long wave_transpose64(unsigned long long x, int 
         const uint32_t r = __shfl_xor((lane & 32) ? lo : hi, 32, 64);
         if (lane & 32) lo = r; else hi = r;
     }
-#pragma unroll
-    for (int k = 16; k >= 1; k >>= 1) {
-        const uint32_t m = k == 16 ? 0x0000ffffu : k == 8 ? 0x00ff00ffu : k == 4 ? 0x0f0f0f0fu : k == 2 ? 0x33333333u : 0x55555555u;
+    auto stage = [&](auto K, uint32_t m) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
         const bool up = (lane & k) != 0;
         // what the partner needs from me, of both halves, packed on complementary bit positions
         const uint32_t send = up ? ((lo & m) | ((hi & m) << k)) : (((lo >> k) & m) | (hi & ~m));
         const uint32_t r = __shfl_xor(send, k, 64);
         if (up) { lo = (lo & ~m) | (r & m); hi = (hi & ~m) | ((r >> k) & m); }
         else    { lo = (lo & m) | ((r & m) << k); hi = (hi & m) | (r & ~m); }
-    }
+    };
+    stage(std::integral_constant<int, 16>{}, 0x0000ffffu);
+    stage(std::integral_constant<int, 8>{}, 0x00ff00ffu);
+    stage(std::integral_constant<int, 4>{}, 0x0f0f0f0fu);
+    stage(std::integral_constant<int, 2>{}, 0x33333333u);
+    stage(std::integral_constant<int, 1>{}, 0x55555555u);
     return ((unsigned long long)hi << 32) | lo;
 }
 
