@@ -8,7 +8,7 @@ import sys
 
 out = sys.argv[1]
 args = sys.argv[2] if len(sys.argv) > 2 else ""
-KEEP = ("pair_", "khop", "cheby", "ring_sum", "ring_gather", "matrix_stats")
+KEEP = ("pair_", "khop", "ms_", "cheby", "ring_sum", "ring_gather", "matrix_stats")
 print(f"# rocprofv3 summary{', command: ' + args if args else ''}")
 print("## kernel-trace --stats (per kernel: calls, average ns, % of GPU time)")
 for f in sorted(glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True)):
