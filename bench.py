@@ -371,17 +371,22 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
         inner = float(sizes[:, :hop].sum(axis=1).mean())                   # |ball_{K-1}| per source
         bytes_sweep = (r1 - r0) * inner * (8.0 + 4.0 * float(g.degree.mean())) + 4.0 * (r1 - r0) * (hop + 1) * n_bins
         bit_parallel = n >= 8192 and hop >= 2 and os.environ.get("HSD_KHOP_MS", "1") != "0"    # the library's own rule (csrc/khop.hip)
-        sweep = {"kernel": ("ms_pull / ms_hist kernels (bit-parallel k-hop sweep, 4096 sources per batch, + per-hop histograms)" if bit_parallel
-                            else "khop_kernel (per-source k-hop sweep + per-hop histograms)"),
-                 "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
-                 "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
-                 "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "bound": ("row gathers out of the Infinity Cache: (hop - 1) * nnz * n / 8 bytes of frontier rows per sweep"
-                           if bit_parallel else "LDS atomics / latency (the graph is L2-resident), not HBM")}
         if bit_parallel:
-            moved = (hop - 1) * (float(g.rowptr[-1]) + 4.0 * n) * 512.0 * ((r1 - r0 + 4095) // 4096)     # gathered + streamed plane rows
-            sweep["plane_bytes_moved"] = moved
-            sweep["plane_GBps"] = round(moved / (sweep_ms * 1e-3) / 1e9, 1)
+            # the bit-parallel sweep does not expand one BFS per source: its bytes are the frontier rows it gathers and the
+            # planes it streams, (hop - 1) pulls per batch of 4096 sources, 512 B per CSR entry and 4 x 512 B per vertex
+            moved = (hop - 1) * (float(g.rowptr[-1]) + 4.0 * n) * 512.0 * ((r1 - r0 + 4095) // 4096)
+            sweep = {"kernel": "ms_pull / ms_hist kernels (bit-parallel k-hop sweep, 4096 sources per batch, + per-hop histograms)",
+                     "ms": round(sweep_ms, 4), "bytes_moved": moved,
+                     "achieved_GBps": round(moved / (sweep_ms * 1e-3) / 1e9, 1),
+                     "frac_of_hbm": round(moved / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bound": "row gathers out of the Infinity Cache (about 8.6 TB/s, MI355X_MICROARCH.md)",
+                     "bytes_alg_per_source_sweep": bytes_sweep,
+                     "note": "bytes_alg_per_source_sweep is SURVEY 8(d)'s figure for one BFS per source; this sweep's own traffic is bytes_moved"}
+        else:
+            sweep = {"kernel": "khop_kernel (per-source k-hop sweep + per-hop histograms)", "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
+                     "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
+                     "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bound": "LDS atomics / latency (the graph is L2-resident), not HBM"}
     t0 = time.perf_counter()
     hdist.allgather_signature(eng, rk.dist, rk.rank, rk.world, via="host" if dryrun else "rccl")   # ONE ncclAllGather over xGMI
     eng.sync()
