@@ -264,6 +264,7 @@ static int ensure_adj_chunks(hsd_ctx *ctx) {
 }
 
 void hsd_khop_ms_release(hsd_ctx *ctx) {
+    if (ctx->ms_stream) (void)hipStreamSynchronize(ctx->ms_stream);    // a launch that failed half way may have left a histogram pass behind
     hsd_dev_free(ctx->d_ms_row_first);
     hsd_dev_free(ctx->d_ms_chunk_row);
     hsd_dev_free(ctx->d_ms_chunk_p0);

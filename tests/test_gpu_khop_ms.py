@@ -120,3 +120,19 @@ def test_ms_sweep_default_for_large_graphs(engine):
     support = engine.signature_support()
     for v in nodes:
         assert np.array_equal(counts[v].astype(np.int64), nr.histogram(int(v), support))
+
+
+@pytest.mark.parametrize("n,hop", [(100000, 3), (50000, 5)])
+def test_ms_sweep_full_size_configs(engine, n, hop):
+    """The target (BA N = 100 000, K = 3) and config 3 (BA N = 50 000, K = 5) at full size: every count of the
+    bit-parallel sweep equals the per-source sweep's, and the ring sizes they imply equal hsd_khop_sizes."""
+    from hsd_amd.graph import barabasi_albert
+    g = barabasi_albert(n, 5, 42)
+    engine.set_graph(g.rowptr, g.col)
+    a = _counts(engine, hop, "1")
+    sizes = a.sum(axis=2, dtype=np.int64)
+    assert np.array_equal(sizes[:3000], engine.khop_sizes(hop, 0, 3000))
+    b = _counts(engine, hop, "0")
+    assert np.array_equal(a, b)
+    # every source sees the whole component at most once
+    assert sizes.sum(axis=1).max() <= n
