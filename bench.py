@@ -370,7 +370,7 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
         sizes = eng.khop_sizes(hop, r0, min(r1, r0 + 2000))                # sample of sources for the ball sizes
         inner = float(sizes[:, :hop].sum(axis=1).mean())                   # |ball_{K-1}| per source
         bytes_sweep = (r1 - r0) * inner * (8.0 + 4.0 * float(g.degree.mean())) + 4.0 * (r1 - r0) * (hop + 1) * n_bins
-        bit_parallel = n >= 8192 and hop >= 2 and os.environ.get("HSD_KHOP_MS", "1") != "0"    # the library's own rule (csrc/khop.hip)
+        bit_parallel = n >= 8192 and hop >= 2 and r1 - r0 >= 2048 and os.environ.get("HSD_KHOP_MS", "1") != "0"    # the library's own rule (csrc/khop.hip)
         if bit_parallel:
             # the bit-parallel sweep does not expand one BFS per source: its bytes are the frontier rows it gathers and the
             # planes it streams, (hop - 1) pulls per batch of 4096 sources, 512 B per CSR entry and 4 x 512 B per vertex

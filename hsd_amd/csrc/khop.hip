@@ -174,7 +174,8 @@ int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, in
     // fill its planes; HSD_KHOP_MS=0 / 1 forces the per-source sweep / the bit-parallel one
     if (hist && !d_sizes && !d_members && hsd_khop_ms_usable(ctx, hop)) {
         const char *em = getenv("HSD_KHOP_MS");
-        if (em ? atoi(em) != 0 : (n >= 8192 && hop >= 2)) return hsd_launch_khop_ms(ctx, hop, r0, r1);
+        // (a batch costs the same for one source as for 4096: short source ranges stay with the per-source sweep)
+        if (em ? atoi(em) != 0 : (n >= 8192 && hop >= 2 && r1 - r0 >= 2048)) return hsd_launch_khop_ms(ctx, hop, r0, r1);
     }
     const int words = (int)((n + 31) / 32);
     const int n_hist = hist ? (hop + 1) * ctx->n_bins : 0;
