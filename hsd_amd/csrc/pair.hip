@@ -73,6 +73,7 @@ struct PairArgs {
     unsigned long long *work;   // += operand words x pairs evaluated (hsd_pair_work), or nullptr
     int *tile_ctr;          // persistent kernel: [8] tiles drawn so far from each XCD's run (zeroed before the launch)
     int ctr_slot;           // which of the context's counter sets this region uses (regions of a row block run side by side)
+    int phase, n_phases;    // host side: this launch covers the tile groups of phase `phase` of `n_phases` (0 / 0: all of them)
     int dbg;                // HSD_DEBUG ablation bits: 1 = no stores, 2 = no arithmetic
     // fused k-nearest consumer (hsd_pair_topk): instead of storing the tile, every value below its
     // row's threshold tau is appended to that row's candidate list
@@ -639,7 +640,9 @@ __device__ inline void wait_vm_young(int young) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int KIND, int NW>
+// TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
+// candidate list instead of being stored (a separate instantiation: the matrix kernels' code is not touched by it).
+template <int KIND, int NW, bool TOPK = false>
 __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs a) {
     using T = typename Elem<KIND>::type;
     using T2 = typename Vec2<T>::type;
@@ -1012,7 +1015,33 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         // ---- stores ----
         asm volatile("" ::: "memory");
         const unsigned long long c_s0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
-        if ((a.dbg & 1) && acc[0][0] != -1.0) {
+        if constexpr (TOPK) {
+            // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (interior tiles
+            // only: i != j, no masks).  tau is read per tile: the host tightens it between the phases of a sweep.
+            gcdouble *tau = (gcdouble *)a.tau;
+            double tj_[TC];
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) tj_[cc] = a.mirror ? tau[j0 + wj + 16 * (cc >> 1) + (cc & 1)] : -1.0;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const int64_t i = i0 + wi + 16 * (r >> 1) + (r & 1);
+                const double ti_ = tau[i];
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) {
+                    const int64_t j = j0 + wj + 16 * (cc >> 1) + (cc & 1);
+                    const double v = acc[r][cc];
+                    if (v <= ti_) {
+                        const int slot = atomicAdd(a.cand_cnt + i, 1);
+                        if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
+                    }
+                    if (v <= tj_[cc]) {
+                        const int slot = atomicAdd(a.cand_cnt + j, 1);
+                        if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
+                    }
+                }
+            }
+            // (vm_seq stays as it is: it must remain a LOWER bound of the operations issued, and these are data dependent)
+        } else if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
         } else {
             // HSD_DEBUG bit 4 (measurement): every tile stores into the first tile's place -- the same store instructions
@@ -1290,13 +1319,18 @@ int tile_edge(const hsd_ctx *ctx) {
 // nullptr (formula order in the kernel) when disabled or on allocation failure.
 // cls: 0 = every tile; 1 = interior tiles only (off the diagonal of a symmetric region, not in a partial last row /
 // column: the persistent kernel's share); 2 = the others (stored with per-element masks by the one-tile kernel).
-const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls, bool part_i, bool part_j, int *count) {
+// phase / n_phases: only the groups whose (group row + group column) % n_phases == phase -- an anti-diagonal sample of the
+// pair space in which every block of rows meets 1 / n_phases of the column blocks (the k-nearest consumer tightens its
+// thresholds between such phases).
+const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls, bool part_i, bool part_j, int *count, int phase = 0,
+                       int n_phases = 1) {
     const char *e = getenv("HSD_SUPERTILE");
     const int S = e ? atoi(e) : 8;
-    if (S <= 1 && cls == 0) { if (count) *count = -1; return nullptr; }
+    if (S <= 1 && cls == 0 && n_phases <= 1) { if (count) *count = -1; return nullptr; }
     const char *ed = getenv("HSD_XCD_DEAL");
     const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
-    const int key = std::max(S, 1) + (deal << 16) + (cls << 20) + ((int)part_i << 24) + ((int)part_j << 25);
+    if (n_phases < 1) n_phases = 1;
+    const int key = std::max(S, 1) + (phase << 8) + (n_phases << 12) + (deal << 16) + (cls << 20) + ((int)part_i << 24) + ((int)part_j << 25);
     for (const auto &c : ctx->tile_lists)
         if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == key) {
             if (count) *count = c.count;
@@ -1308,6 +1342,7 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
     std::vector<size_t> group_begin;
     for (int sr = 0; sr < tiles_i; sr += G)
         for (int sc = sym ? sr : 0; sc < tiles_j; sc += G) {
+            if ((sr / G + sc / G) % n_phases != phase) continue;
             group_begin.push_back(order.size());
             for (int ti = sr; ti < std::min(sr + G, tiles_i); ++ti)
                 for (int tj = std::max(sc, sym ? ti : 0); tj < std::min(sc + G, tiles_j); ++tj) {
@@ -1332,14 +1367,14 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
         if (count) *count = -1;
         return nullptr;
     }
-    if (ctx->tile_lists.size() >= 12) { (void)hipFree(ctx->tile_lists.front().d); ctx->tile_lists.erase(ctx->tile_lists.begin()); }
+    if (ctx->tile_lists.size() >= 64) { (void)hipFree(ctx->tile_lists.front().d); ctx->tile_lists.erase(ctx->tile_lists.begin()); }
     ctx->tile_lists.push_back({tiles_i, tiles_j, sym, key, d, (int)order.size()});
     return reinterpret_cast<const int2 *>(d);
 }
 
-template <int KIND, int NW>
+template <int KIND, int NW, bool TOPK = false>
 hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
-    auto kern = pair_stream_kernel<KIND, NW>;
+    auto kern = pair_stream_kernel<KIND, NW, TOPK>;
     constexpr int CH = stream_chunk_cols(KIND, NW);
     constexpr int BT = NW == 4 ? 128 : 64;
     const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 +
@@ -1396,15 +1431,15 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
 }
 
 // The persistent kernel takes every region whose operand slices and output rows are 16-byte aligned (direct-to-LDS
-// loads, vector stores), except the fused k-nearest consumer and the fp64 zero-pad fallback (its two fp64 accumulator
-// sets do not fit 8 x 8 pairs per lane).  HSD_STREAM=0 or an explicit HSD_TILE: the one-tile-per-workgroup kernel for
+// loads, vector stores), except the fp64 zero-pad fallback (its two fp64 accumulator sets do not fit 8 x 8 pairs per
+// lane); the fused k-nearest consumer runs its own instantiation (TOPK).  HSD_STREAM=0 or an explicit HSD_TILE: the one-tile-per-workgroup kernel for
 // every tile (A/B measurements; the tests run both and compare them bit for bit).
 int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
     if (const char *ew = getenv("HSD_STREAM")) if (atoi(ew) == 0) return 0;
     if (getenv("HSD_TILE")) return 0;
-    if (a.tau || ctx->mode == PAIR_ZP_F64) return 0;
-    const bool aligned = (a.i_begin % 4 == 0) && (a.j_begin % 4 == 0) && (a.npad % 4 == 0) && (a.ld % 2 == 0) &&
-                         (reinterpret_cast<uintptr_t>(a.out) % 16 == 0);
+    if (ctx->mode == PAIR_ZP_F64) return 0;
+    const bool aligned = (a.i_begin % 4 == 0) && (a.j_begin % 4 == 0) && (a.npad % 4 == 0) &&
+                         (a.tau || ((a.ld % 2 == 0) && (reinterpret_cast<uintptr_t>(a.out) % 16 == 0)));
     if (!aligned) return 0;
     // a resident workgroup needs a few dozen tiles to amortise its start-up and to level the tail (measured at ER N = 10k,
     // 3160 tiles for 512 workgroups: zero-pad 0.210 ms against 0.178 ms with one 64 x 64 tile per workgroup); HSD_STREAM=1 forces it
@@ -1449,8 +1484,8 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
         // interior tiles: the persistent kernel; diagonal and partial tiles: the one-tile kernel with its masked stores
         // (the two launches write disjoint tiles; the second is tiny and runs in the tail of the first)
         int n_in = -1, n_mask = -1;
-        const int2 *l_in = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 1, part_i, part_j, &n_in);
-        const int2 *l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 2, part_i, part_j, &n_mask);
+        const int2 *l_in = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 1, part_i, part_j, &n_in, a.phase, a.n_phases);
+        const int2 *l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 2, part_i, part_j, &n_mask, a.phase, a.n_phases);
         if (n_in >= 0 && n_mask >= 0) {
             const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
             PairArgs b = a;
@@ -1458,16 +1493,24 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
             b.n_aux = ctx->n_seg + ((wass ? a.point != nullptr : true) ? 1 : 0);
             // LDS budget of the persistent kernel (2 workgroups per CU): two tiles x three vectors x 2 KiB; deeper hierarchies
             // (more than two compared histogram layers + ring 0) take the one-tile kernel for every tile
-            if (b.n_aux > 3) { n_mask += n_in; n_in = 0; l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &n_mask); }
+            if (b.n_aux > 3) { n_in = 0; l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &n_mask, a.phase, a.n_phases); }
             if (n_in > 0) {
                 b.tiles = l_in;
                 b.ntiles = n_in;
-                switch (ctx->mode) {
-                    case PAIR_L1_F64: e = launch_stream<K_L1, 4>(ctx, b, stream); break;
-                    case PAIR_SAD_U32: e = launch_stream<K_SAD, 4>(ctx, b, stream); break;
-                    case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4>(ctx, b, stream); break;
-                    default: e = launch_stream<K_DOT, 4>(ctx, b, stream); break;
-                }
+                if (a.tau)
+                    switch (ctx->mode) {
+                        case PAIR_L1_F64: e = launch_stream<K_L1, 4, true>(ctx, b, stream); break;
+                        case PAIR_SAD_U32: e = launch_stream<K_SAD, 4, true>(ctx, b, stream); break;
+                        case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4, true>(ctx, b, stream); break;
+                        default: e = launch_stream<K_DOT, 4, true>(ctx, b, stream); break;
+                    }
+                else
+                    switch (ctx->mode) {
+                        case PAIR_L1_F64: e = launch_stream<K_L1, 4>(ctx, b, stream); break;
+                        case PAIR_SAD_U32: e = launch_stream<K_SAD, 4>(ctx, b, stream); break;
+                        case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4>(ctx, b, stream); break;
+                        default: e = launch_stream<K_DOT, 4>(ctx, b, stream); break;
+                    }
             }
             if (e == hipSuccess && n_mask > 0) {
                 PairArgs c = a;
@@ -1482,6 +1525,13 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
     }
     a.ntiles = (int)nb;
     a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, nullptr);
+    if (a.n_phases > 1) {
+        int cnt = -1;
+        a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &cnt, a.phase, a.n_phases);
+        if (cnt < 0) return hsd_fail(ctx, HSD_ERR_HIP, "tile list of a sweep phase could not be allocated");
+        a.ntiles = cnt;
+        if (cnt == 0) return HSD_OK;
+    }
     e = launch_one_tile(ctx, a, BT, stream);
     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
     return HSD_OK;
@@ -1532,35 +1582,81 @@ __global__ void pack_u16_kernel(const uint32_t *__restrict__ X32, int64_t npad, 
     }
 }
 
-// ---- fused k-nearest consumer --------------------------------------------------------------
-// tau[i] = k-th smallest of D[i, cols) over a column subset (self excluded): an upper bound of the
-// true k-th nearest distance.  One workgroup per row; bitonic sort of the subset in LDS.
-__global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__restrict__ S, int64_t ld, int M, int64_t row0, int k,
-                                                            double *__restrict__ tau) {
-    extern __shared__ double tk_sh[];
-    double *sh = tk_sh;
-    const int64_t r = blockIdx.x;
-    int p2 = 1;
-    while (p2 < M) p2 <<= 1;
-    for (int t = threadIdx.x; t < p2; t += 256) sh[t] = t < M ? S[r * ld + t] : INFINITY;
-    __syncthreads();
-    for (int kk = 2; kk <= p2; kk <<= 1)
-        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (int t = threadIdx.x; t < p2; t += 256) {
-                const int x = t ^ jj;
-                if (x > t) {
-                    const double u = sh[t], v = sh[x];
-                    const bool up = (t & kk) == 0;
-                    if ((u > v) == up) { sh[t] = v; sh[x] = u; }
-                }
-            }
-            __syncthreads();
+// The next (value, index) pair of a list in lexicographic order after (last_v, last_i), found by ONE WAVE: every lane scans
+// its share of the list, six exchange steps pick the minimum.  ci == nullptr: the position is the index (plain values).
+__device__ inline void wave_lex_next(const double *__restrict__ cv, const int *__restrict__ ci, int c, double last_v, int last_i, int lane,
+                                     double &ov, int &oi) {
+    double bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = lane; t < c; t += 64) {
+        const double v = cv[t];
+        const int i = ci ? ci[t] : t;
+        const bool after = v > last_v || (v == last_v && i > last_i);
+        if (after && (v < bv || (v == bv && i < bi))) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v = __shfl_xor(bv, o, 64);
+        const int i = __shfl_xor(bi, o, 64);
+        if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    ov = bv;
+    oi = bi;
+}
+
+// The same with the list held in registers (E entries per lane, loaded once): the rounds then cost no memory access.
+template <int E>
+struct WaveList {
+    double v[E];
+    int i[E];
+    __device__ inline void load(const double *__restrict__ cv, const int *__restrict__ ci, int c, int lane) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int t = lane + 64 * e;
+            v[e] = t < c ? cv[t] : INFINITY;
+            i[e] = t < c ? (ci ? ci[t] : t) : 0x7fffffff;
         }
-    // The row's own node may be among the sampled columns (its distance is an exact 0 and sorts
-    // first): taking the (k+1)-th smallest keeps tau an upper bound of the k-th nearest OTHER node
-    // whether or not it is.  Slightly inflated: the sweep may evaluate a pair from the mirrored
-    // tile, whose fp64 sums are accumulated in another order (symmetric KL).
-    if (threadIdx.x == 0) tau[row0 + r] = sh[k] + fabs(sh[k]) * 1e-12;
+    }
+    __device__ inline void next(double last_v, int last_i, double &ov, int &oi) const {
+        double bv = INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool after = v[e] > last_v || (v[e] == last_v && i[e] > last_i);
+            if (after && (v[e] < bv || (v[e] == bv && i[e] < bi))) { bv = v[e]; bi = i[e]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double xv = __shfl_xor(bv, o, 64);
+            const int xi = __shfl_xor(bi, o, 64);
+            if (xv < bv || (xv == bv && xi < bi)) { bv = xv; bi = xi; }
+        }
+        ov = bv;
+        oi = bi;
+    }
+};
+
+// tau[row] = the (k+1)-th smallest of the row's M sampled distances, slightly inflated.  One wave per row, k + 1 rounds of
+// "next smallest" (k is small against M; a bitonic sort of the sample in LDS took 2.2 ms for 100 000 rows of 1024).
+// The row's own node may be among the sampled columns (its distance is an exact 0 and comes first): the (k+1)-th smallest
+// keeps tau an upper bound of the k-th nearest OTHER node whether or not it is.  Inflated: the sweep may evaluate a pair
+// from the mirrored tile, whose fp64 sums are accumulated in another order (symmetric KL).
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__restrict__ S, int64_t ld, int M, int64_t row0, int64_t rows, int k,
+                                                            double *__restrict__ tau) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const double *sv = S + r * ld;
+    double last_v = -INFINITY;
+    int last_i = -1;
+    if (M <= 1024) {
+        WaveList<16> wl;
+        wl.load(sv, nullptr, M, lane);
+        for (int q = 0; q <= k; ++q) wl.next(last_v, last_i, last_v, last_i);
+    } else {
+        for (int q = 0; q <= k; ++q) wave_lex_next(sv, nullptr, M, last_v, last_i, lane, last_v, last_i);
+    }
+    if (lane == 0) tau[row0 + r] = last_v + fabs(last_v) * 1e-12;
 }
 
 __global__ void fill_columns_kernel(double *__restrict__ S, int64_t ld, int64_t rows, int c_begin, int c_end, double v) {
@@ -1569,48 +1665,74 @@ __global__ void fill_columns_kernel(double *__restrict__ S, int64_t ld, int64_t 
     for (int c = c_begin; c < c_end; ++c) S[r * ld + c] = v;
 }
 
-// The k smallest (value, index) pairs of each row's candidate list, ascending, ties by index:
-// k rounds of "next lexicographic minimum" (the lists are short).  flag[0] |= 1 on overflow or
-// on a list shorter than k.
+// The k smallest (value, index) pairs of each row's candidate list, ascending, ties by index: one wave per row, k rounds
+// of "next lexicographic minimum" (the lists are short).  flag[0] |= 1 on overflow or on a list shorter than k.
 __global__ __launch_bounds__(256) void topk_select_kernel(const int *__restrict__ cnt, const int *__restrict__ cidx,
                                                          const double *__restrict__ cval, int cap, int64_t row0, int64_t rows, int k,
                                                          int *__restrict__ out_idx, double *__restrict__ out_val, int *__restrict__ flag) {
-    __shared__ double rv[256];
-    __shared__ int ri[256];
-    const int64_t row = row0 + blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t lr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lr >= rows) return;
+    const int64_t row = row0 + lr;
     const int c = cnt[row];
     if (c > cap || c < k) {
-        if (threadIdx.x == 0) atomicOr(flag, 1);
+        if (lane == 0) atomicOr(flag, 1);
         return;
     }
     const int *ci = cidx + row * cap;
     const double *cv = cval + row * cap;
     double last_v = -INFINITY;
     int last_i = -1;
+    if (c <= 512) {
+        WaveList<8> wl;
+        wl.load(cv, ci, c, lane);
+        for (int q = 0; q < k; ++q) {
+            wl.next(last_v, last_i, last_v, last_i);
+            if (lane == 0) { out_idx[lr * (int64_t)k + q] = last_i; out_val[lr * (int64_t)k + q] = last_v; }
+        }
+        return;
+    }
     for (int q = 0; q < k; ++q) {
-        double bv = INFINITY;
-        int bi = 0x7fffffff;
-        for (int t = threadIdx.x; t < c; t += 256) {
-            const double v = cv[t];
-            const int i = ci[t];
-            const bool after = v > last_v || (v == last_v && i > last_i);
-            if (after && (v < bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        wave_lex_next(cv, ci, c, last_v, last_i, lane, last_v, last_i);
+        if (lane == 0) { out_idx[lr * (int64_t)k + q] = last_i; out_val[lr * (int64_t)k + q] = last_v; }
+    }
+}
+
+// Between two phases of the sweep: a row whose list has grown beyond k entries keeps its k smallest (value, index) pairs
+// and takes the k-th value as its new threshold -- still an upper bound of its k-th nearest, and every later candidate
+// must beat it.  One wave per row.  Lists that overflowed are left alone (the select kernel reports them, the host retries).
+__global__ __launch_bounds__(256) void topk_compact_kernel(int *__restrict__ cnt, int *__restrict__ cidx, double *__restrict__ cval, int cap,
+                                                          int64_t rows, int k, double *__restrict__ tau) {
+    extern __shared__ double cmp_sh[];                 // per wave: k values, then k indices
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *sel_v = cmp_sh + (size_t)w * k;
+    int *sel_i = reinterpret_cast<int *>(cmp_sh + (size_t)4 * k) + (size_t)w * k;
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= rows) return;
+    const int c = cnt[row];
+    if (c > cap || c <= k) return;
+    int *ci = cidx + row * cap;
+    double *cv = cval + row * cap;
+    double last_v = -INFINITY;
+    int last_i = -1;
+    if (c <= 512) {
+        WaveList<8> wl;
+        wl.load(cv, ci, c, lane);
+        for (int q = 0; q < k; ++q) {
+            wl.next(last_v, last_i, last_v, last_i);
+            if (lane == 0) { sel_v[q] = last_v; sel_i[q] = last_i; }
         }
-        rv[threadIdx.x] = bv;
-        ri[threadIdx.x] = bi;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                const double v = rv[threadIdx.x + o];
-                const int i = ri[threadIdx.x + o];
-                if (v < rv[threadIdx.x] || (v == rv[threadIdx.x] && i < ri[threadIdx.x])) { rv[threadIdx.x] = v; ri[threadIdx.x] = i; }
-            }
-            __syncthreads();
+    } else {
+        for (int q = 0; q < k; ++q) {
+            wave_lex_next(cv, ci, c, last_v, last_i, lane, last_v, last_i);
+            if (lane == 0) { sel_v[q] = last_v; sel_i[q] = last_i; }
         }
-        last_v = rv[0];
-        last_i = ri[0];
-        if (threadIdx.x == 0) { out_idx[blockIdx.x * (int64_t)k + q] = last_i; out_val[blockIdx.x * (int64_t)k + q] = last_v; }
-        __syncthreads();
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < k; t += 64) { cv[t] = sel_v[t]; ci[t] = sel_i[t]; }
+    if (lane == 0) {
+        cnt[row] = k;
+        tau[row] = fmin(tau[row], last_v + fabs(last_v) * 1e-12);   // (inflated like the first threshold: mirrored evaluation order)
     }
 }
 
@@ -2119,12 +2241,26 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     a.i_begin = r0; a.i_end = r1;
 
     int64_t M = std::min<int64_t>(n, std::max<int64_t>(1024, 4 * (int64_t)k));
-    int64_t cap = std::min<int64_t>(n, std::max<int64_t>(256, 4 * (int64_t)k * n / M + 64));
+    // A large sweep runs in phases (anti-diagonal samples of the tile groups, tile_order): after each one every row keeps
+    // its k best and tightens its threshold, so that the candidates appended per row fall from ~ k n / M to
+    // ~ k n / (M P) + k (1 + 1/2 + .. + 1/(P-1)).  HSD_TOPK_PHASES forces a count (tests).
+    int n_phases = 1;
+    {
+        const int64_t t128 = (rows + 127) / 128, tiles = t128 * ((n + 127) / 128);
+        const int cus = std::max(1, ctx->prop.multiProcessorCount);
+        while (n_phases < 8 && tiles / (2 * n_phases) >= 64 * (int64_t)cus) n_phases *= 2;
+        if (const char *ep = getenv("HSD_TOPK_PHASES")) n_phases = std::max(1, std::min(16, atoi(ep)));
+    }
+    // list capacity: the expected candidates of the first phase (k / M of a row's n / P columns) with room for rows of many
+    // equal distances (the integer zero-pad distances tie by the hundred); an overflow anywhere costs a whole retry
+    int64_t cap = std::min<int64_t>(n, n_phases > 1 ? std::max<int64_t>(2048, 8 * (int64_t)k * n / (M * n_phases) + 8 * k + 64)
+                                                    : std::max<int64_t>(256, 4 * (int64_t)k * n / M + 64));
+    if (const char *ec = getenv("HSD_TOPK_CAP")) cap = std::min<int64_t>(n, std::max<int64_t>(k + 1, atoll(ec)));   // test hook
     int rc = HSD_OK;
     for (int attempt = 0; attempt < 3 && rc == HSD_OK; ++attempt) {
         if (attempt == 1) { M = std::min<int64_t>(n, 4 * M); cap = std::min<int64_t>(n, 8 * cap); }
         if (attempt == 2) { M = std::min<int64_t>(n, 16384); cap = n; }
-        M = std::min<int64_t>(M, 16384);                        // threshold sort lives in LDS (128 KiB)
+        M = std::min<int64_t>(M, 16384);
         const int64_t ldS = (M + 127) / 128 * 128;
         // scratch: one grow-only arena per context (allocating gigabytes per call would dominate)
         size_t off = 0;
@@ -2167,33 +2303,39 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
         }
         if (rc == HSD_OK && e == hipSuccess) {
             const int Ms = n_sub * 128;
-            int p2 = 1;
-            while (p2 < Ms) p2 <<= 1;
-            const size_t lds = (size_t)p2 * sizeof(double);
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(topk_threshold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)rows), dim3(256), lds, ctx->stream, d_S, ldS, Ms, r0, k, d_tau - r0);
+            hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, Ms, r0, rows, k, d_tau - r0);
         }
         // 2. sweep: square on the diagonal (both rows of a pair are ours) + the blocks left and right of it
-        if (rc == HSD_OK && e == hipSuccess) {
+        for (int ph = 0; ph < n_phases && rc == HSD_OK && e == hipSuccess; ++ph) {
             PairArgs b = a;
             b.out = nullptr; b.ld = 0;
             b.tau = d_tau - r0; b.cand_cnt = d_cnt - r0; b.cand_idx = d_idx - r0 * cap; b.cand_val = d_val - r0 * cap; b.cand_cap = (int)cap;
+            b.phase = ph; b.n_phases = n_phases;
             b.j_begin = r0; b.j_end = r1; b.sym = 1; b.mirror = 1; b.swap = 0;
             const int BT = tile_edge(ctx);
             rc = launch_region(ctx, b, BT, ctx->stream);
             b.sym = 0; b.mirror = 0;
             if (rc == HSD_OK && r0 > 0) { b.j_begin = 0; b.j_end = r0; rc = launch_region(ctx, b, BT, ctx->stream); }
             if (rc == HSD_OK && r1 < n) { b.j_begin = r1; b.j_end = n; rc = launch_region(ctx, b, BT, ctx->stream); }
+            if (rc == HSD_OK && ph + 1 < n_phases)
+                hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), (size_t)4 * k * 12, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, d_tau);
         }
         // 3. select
         int flag[4] = {0, 0, 0, 0};
         if (rc == HSD_OK && e == hipSuccess) {
-            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap,
+            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap,
                                (int64_t)0, rows, k, d_oidx, d_oval, ctx->d_flag);
             e = hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = hipGetLastError();
+        }
+        if (getenv("HSD_TOPK_VERBOSE") && rc == HSD_OK && e == hipSuccess) {
+            std::vector<int> hc((size_t)rows);
+            (void)hipMemcpy(hc.data(), d_cnt, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost);
+            int64_t mx = 0, over = 0;
+            for (int v : hc) { mx = std::max<int64_t>(mx, v); over += v > cap; }
+            fprintf(stderr, "[hsd topk] attempt %d: M %lld, phases %d, capacity %lld, longest list %lld, rows over capacity %lld\n", attempt,
+                    (long long)M, n_phases, (long long)cap, (long long)mx, (long long)over);
         }
         const bool again = rc == HSD_OK && e == hipSuccess && (flag[0] & 1) && attempt < 2;
         if (rc == HSD_OK && e == hipSuccess && !(flag[0] & 1)) {

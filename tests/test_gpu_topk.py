@@ -67,3 +67,55 @@ def test_topk_all_ties_and_errors(engine):
     engine.pair_prepare(1, 0, 0, 2, 0.5, False)
     with pytest.raises(NotImplementedError):
         engine.pair_topk(3)                      # plain KL is asymmetric: not offered
+
+
+@pytest.mark.parametrize("mode,k", [((0, 1, 0, 1), 10), ((0, 0, 0, 2), 16), ((2, 0, 0, 2), 5)])
+@pytest.mark.parametrize("phases", ["1", "3", "8"])
+def test_topk_phased_sweep_on_the_persistent_kernel(engine, mode, k, phases):
+    """The large-N schedule at a size the full matrix can check: persistent kernel (HSD_STREAM=1) with its
+    candidate epilogue, the sweep cut into phases with the thresholds tightened in between."""
+    import os
+    from hsd_amd.graph import erdos_renyi, connect_components
+    n = 3301
+    g = connect_components(erdos_renyi(n, 0.004, 5), 5)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(2)
+    engine.pair_prepare(*mode)
+    D = engine.pair_rows_host()
+    ridx, rval = _reference_topk(D, k)
+    os.environ["HSD_STREAM"] = "1"
+    os.environ["HSD_TOPK_PHASES"] = phases
+    try:
+        idx, val = engine.pair_topk(k)
+        a, b = 1024, 2560                                  # an aligned row block: square + both rectangles, all phased
+        idx2, val2 = engine.pair_topk(k, a, b)
+    finally:
+        os.environ.pop("HSD_STREAM", None)
+        os.environ.pop("HSD_TOPK_PHASES", None)
+    assert np.array_equal(val, rval)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(idx2, ridx[a:b])
+    if mode[0] == 2:
+        assert np.allclose(val2, rval[a:b], rtol=1e-10, atol=0)
+    else:
+        assert np.array_equal(val2, rval[a:b])
+
+
+def test_topk_target_size_without_the_matrix(engine):
+    """BA N = 100 000 (the target graph), zero-pad W1, 20 nearest: the phased sweep against rows of the full matrix."""
+    from hsd_amd.graph import barabasi_albert
+    n, k = 100000, 20
+    g = barabasi_albert(n, 5, 42)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 1, 0, 2)
+    idx, val = engine.pair_topk(k)
+    M = engine.pair_rows_device()
+    try:
+        for r in (0, 1, 127, 128, 4097, n // 2, n - 1):
+            d = M.rows_to_host(r, r + 1)[0].copy()
+            d[r] = np.inf
+            order = np.lexsort((np.arange(n), d))[:k]
+            assert np.array_equal(order, idx[r]) and np.array_equal(d[order], val[r])
+    finally:
+        M.free()
