@@ -119,3 +119,24 @@ def test_topk_target_size_without_the_matrix(engine):
             assert np.array_equal(order, idx[r]) and np.array_equal(d[order], val[r])
     finally:
         M.free()
+
+
+def test_topk_phased_sweep_overflow_retry(engine):
+    """Lists far too short for the first phase: the overflow is reported by the selection and the call retries with
+    larger capacities (the last attempt holds n entries per row)."""
+    import os
+    from hsd_amd.graph import erdos_renyi, connect_components
+    n, k = 2200, 8
+    g = connect_components(erdos_renyi(n, 0.005, 9), 9)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(2)
+    engine.pair_prepare(0, 1, 0, 1)
+    D = engine.pair_rows_host()
+    ridx, rval = _reference_topk(D, k)
+    os.environ.update(HSD_STREAM="1", HSD_TOPK_PHASES="4", HSD_TOPK_CAP=str(k + 1))
+    try:
+        idx, val = engine.pair_topk(k)
+    finally:
+        for v in ("HSD_STREAM", "HSD_TOPK_PHASES", "HSD_TOPK_CAP"):
+            os.environ.pop(v, None)
+    assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
