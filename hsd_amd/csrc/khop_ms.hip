@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void ms_partial_kernel(const int64_t *__restri
 __global__ __launch_bounds__(256) void ms_pull_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int n,
                                                      int nsrc, const unsigned long long *__restrict__ F,
                                                      unsigned long long *__restrict__ V, unsigned long long *__restrict__ Fn /* or null */,
+                                                     unsigned long long *__restrict__ Fzero /* last hop: plane to clear, or null */,
                                                      unsigned long long *__restrict__ RT, int64_t ldn,
                                                      const int32_t *__restrict__ row_first /* or null */,
                                                      const unsigned long long *__restrict__ P) {
@@ -125,8 +126,15 @@ __global__ __launch_bounds__(256) void ms_pull_kernel(const int64_t *__restrict_
                 }
             }
             nw = acc & ~vis;
-            if (nw) V[(int64_t)i * MS_WORDS + lane] = vis | nw;
-            if (Fn) Fn[(int64_t)i * MS_WORDS + lane] = nw;
+            if (Fn) {
+                if (nw) V[(int64_t)i * MS_WORDS + lane] = vis | nw;
+                Fn[(int64_t)i * MS_WORDS + lane] = nw;
+            } else {
+                // last hop of the batch: V is dead -- leave it (and the frontier plane nobody reads any more) cleared for the
+                // next batch instead of two 50-100 MB memsets between the batches
+                if (vis) V[(int64_t)i * MS_WORDS + lane] = 0ull;
+                if (Fzero) Fzero[(int64_t)i * MS_WORDS + lane] = 0ull;
+            }
         }
         tile[wv * (MS_ROWS / 4) + r][lane] = nw;
     }
@@ -321,7 +329,11 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
         const int nsrc = (int)std::min<int64_t>(MS_BATCH, r1 - b0);
         const int set = overlap ? batch & 1 : 0;
         unsigned long long *RT = RT0 + (size_t)set * n_planes * rt_plane;
-        HSD_HIP(ctx, hipMemsetAsync(V, 0, (size_t)(hop >= 2 ? 2 : 1) * plane * sizeof(unsigned long long), ctx->stream));
+        // V and Fa start cleared: by memset for the first batch, afterwards by the previous batch's last pull (which can
+        // clear Fa only if it did not read it: the frontier of hop k sits in Fa for even k)
+        const bool fa_cleared_by_pull = hop >= 3 && (hop & 1);
+        if (batch == 0 || hop < 2) HSD_HIP(ctx, hipMemsetAsync(V, 0, (size_t)(hop >= 2 ? 2 : 1) * plane * sizeof(unsigned long long), ctx->stream));
+        else if (!fa_cleared_by_pull) HSD_HIP(ctx, hipMemsetAsync(Fa, 0, (size_t)plane * sizeof(unsigned long long), ctx->stream));
         if (n_planes)                    // rings 2..hop are accumulated by atomics: clear their rows (rings 0 / 1 are stored)
             HSD_HIP(ctx, hipMemsetAsync(ctx->d_counts + (size_t)b0 * L * B, 0, (size_t)nsrc * L * B * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(ms_ring01_kernel, dim3((unsigned)nsrc), dim3(64), (size_t)B * sizeof(uint32_t), ctx->stream, ctx->d_rowptr,
@@ -333,7 +345,7 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
                 hipLaunchKernelGGL(ms_partial_kernel, dim3((unsigned)((ctx->ms_n_chunks + 3) / 4)), dim3(256), 0, ctx->stream, ctx->d_rowptr,
                                    ctx->d_col, F, ctx->d_ms_chunk_row, ctx->d_ms_chunk_p0, ctx->ms_n_chunks, P);
             hipLaunchKernelGGL(ms_pull_kernel, dim3(n_rb), dim3(256), 0, ctx->stream, ctx->d_rowptr, ctx->d_col, (int)n, nsrc, F, V,
-                               k < hop ? Fn : nullptr, RT + (size_t)(k - 2) * rt_plane, ldn,
+                               k < hop ? Fn : nullptr, (k == hop && fa_cleared_by_pull) ? Fa : nullptr, RT + (size_t)(k - 2) * rt_plane, ldn,
                                ctx->ms_n_chunks ? ctx->d_ms_row_first : nullptr, P);
             std::swap(F, Fn);
         }
