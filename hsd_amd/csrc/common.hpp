@@ -189,8 +189,8 @@ static inline int hsd_raise_lds_limit(hsd_ctx *ctx, const void *kern, size_t byt
 // implemented in the per-kernel translation units
 int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, int32_t *d_sizes,
                     const int64_t *d_offsets, int32_t *d_members);
-int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1);
-bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop);
+int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, uint32_t *counts = nullptr, const int32_t *node_bin = nullptr, int n_bins = 0);
+bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop, int n_bins);
 void hsd_khop_ms_release(hsd_ctx *ctx);
 void hsd_release_operands(hsd_ctx *ctx);
 extern "C" void hsd_heat_release_internal(hsd_ctx *ctx);

@@ -283,14 +283,17 @@ void hsd_khop_ms_release(hsd_ctx *ctx) {
 }
 
 // can the bit-parallel sweep serve this histogram build?  (LDS: 64 sources x n_bins counters per workgroup)
-bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop) {
+bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop, int n_bins) {
     const size_t lds_cap = ctx->prop.maxSharedMemoryPerMultiProcessor ? ctx->prop.maxSharedMemoryPerMultiProcessor : 65536;
-    return hop >= 0 && (size_t)64 * (ctx->n_bins | 1) * sizeof(uint32_t) <= std::min<size_t>(lds_cap, 128 * 1024);
+    return hop >= 0 && (size_t)64 * (n_bins | 1) * sizeof(uint32_t) <= std::min<size_t>(lds_cap, 128 * 1024);
 }
 
-int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
+// counts: [.][hop + 1][n_bins] indexed by the GLOBAL source id (the caller offsets the pointer for a row range);
+// node_bin: [n] bin of every vertex.  The context's own histogram tensor by default; hsd_khop_sizes passes one bin.
+int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, uint32_t *counts, const int32_t *node_bin, int n_bins) {
     const int64_t n = ctx->n;
-    const int L = hop + 1, B = ctx->n_bins;
+    if (!counts) { counts = ctx->d_counts; node_bin = ctx->d_node_bin; n_bins = ctx->n_bins; }
+    const int L = hop + 1, B = n_bins;
     if (r1 <= r0) return HSD_OK;
     int rc = ensure_adj_chunks(ctx);
     if (rc) return rc;
@@ -335,9 +338,9 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
         if (batch == 0 || hop < 2) HSD_HIP(ctx, hipMemsetAsync(V, 0, (size_t)(hop >= 2 ? 2 : 1) * plane * sizeof(unsigned long long), ctx->stream));
         else if (!fa_cleared_by_pull) HSD_HIP(ctx, hipMemsetAsync(Fa, 0, (size_t)plane * sizeof(unsigned long long), ctx->stream));
         if (n_planes)                    // rings 2..hop are accumulated by atomics: clear their rows (rings 0 / 1 are stored)
-            HSD_HIP(ctx, hipMemsetAsync(ctx->d_counts + (size_t)b0 * L * B, 0, (size_t)nsrc * L * B * sizeof(uint32_t), ctx->stream));
+            HSD_HIP(ctx, hipMemsetAsync(counts + (int64_t)b0 * L * B, 0, (size_t)nsrc * L * B * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(ms_ring01_kernel, dim3((unsigned)nsrc), dim3(64), (size_t)B * sizeof(uint32_t), ctx->stream, ctx->d_rowptr,
-                           ctx->d_col, b0, hop, ctx->d_node_bin, B, ctx->d_counts, V, Fa);
+                           ctx->d_col, b0, hop, node_bin, B, counts, V, Fa);
         if (overlap && batch >= 2) HSD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ms_ev_hist[set], 0));   // this set's planes have been read
         unsigned long long *F = Fa, *Fn = Fb;
         for (int k = 2; k <= hop; ++k) {
@@ -359,7 +362,7 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
             const int words_used = (nsrc + 63) / 64;
             const int parts = std::max(1, std::min(8, 2 * ctx->prop.multiProcessorCount / std::max(1, words_used * n_planes)));
             hipLaunchKernelGGL(ms_hist_kernel, dim3((unsigned)words_used, (unsigned)parts, (unsigned)n_planes), dim3(MS_HIST_THREADS), lds_hist,
-                               hs, RT, ldn, rt_plane, (int)n, parts, 2, L, ctx->d_node_bin, B, b0, nsrc, ctx->d_counts);
+                               hs, RT, ldn, rt_plane, (int)n, parts, 2, L, node_bin, B, b0, nsrc, counts);
             if (overlap) HSD_HIP(ctx, hipEventRecord(ctx->ms_ev_hist[set], ctx->ms_stream));
         }
         hipError_t e = hipGetLastError();

@@ -131,8 +131,35 @@ def test_ms_sweep_full_size_configs(engine, n, hop):
     engine.set_graph(g.rowptr, g.col)
     a = _counts(engine, hop, "1")
     sizes = a.sum(axis=2, dtype=np.int64)
-    assert np.array_equal(sizes[:3000], engine.khop_sizes(hop, 0, 3000))
+    os.environ["HSD_KHOP_MS"] = "0"
+    try:
+        per_source = engine.khop_sizes(hop, 0, 3000)
+    finally:
+        os.environ.pop("HSD_KHOP_MS", None)
+    assert np.array_equal(sizes[:3000], per_source)
+    assert np.array_equal(sizes, engine.khop_sizes(hop))          # default for a graph of this size: one-bin bit-parallel sweep
     b = _counts(engine, hop, "0")
     assert np.array_equal(a, b)
     # every source sees the whole component at most once
     assert sizes.sum(axis=1).max() <= n
+
+
+@pytest.mark.parametrize("name", ["karate", "er_sparse", "ba5000"])
+@pytest.mark.parametrize("hop", [0, 1, 2, 4])
+def test_ring_sizes_by_the_one_bin_sweep(engine, name, hop):
+    """hsd_khop_sizes (hierarchical degree, SIR labels) through the bit-parallel sweep with a single bin, whole graph and a
+    row range, against the per-source sweep and the C oracle."""
+    from oracle import c_oracle as corc
+    g = _graphs()[name]
+    engine.set_graph(g.rowptr, g.col)
+    n = g.n_node
+    out = {}
+    for ms in ("0", "1"):
+        os.environ["HSD_KHOP_MS"] = ms
+        try:
+            out[ms] = (engine.khop_sizes(hop), engine.khop_sizes(hop, n // 3, n - 5))
+        finally:
+            os.environ.pop("HSD_KHOP_MS", None)
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    assert np.array_equal(out["1"][0], corc.khop_sizes(g.rowptr, g.col, hop))
+    assert np.array_equal(out["1"][1], out["1"][0][n // 3:n - 5])
