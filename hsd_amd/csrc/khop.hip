@@ -133,7 +133,7 @@ __global__ __launch_bounds__(KH_THREADS) void khop_kernel(
                     const int b = __ffs(nw) - 1;
                     nw &= nw - 1;
                     const int v = (w << 5) + b;
-                    queue[pos] = v;
+                    if (k < hop) queue[pos] = v;          // the last ring is never expanded: no frontier entry
                     if (mem_out) mem_out[pos] = v;
                     if (counts) atomicAdd(&hist[k * n_bins + node_bin[v]], 1u);
                     ++pos;
