@@ -1016,6 +1016,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         asm volatile("" ::: "memory");
         const unsigned long long c_s0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
         if constexpr (TOPK) {
+          if (!((a.dbg & 1) && acc[0][0] != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
             // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (interior tiles
             // only: i != j, no masks).  tau is read per tile: the host tightens it between the phases of a sweep.
             gcdouble *tau = (gcdouble *)a.tau;
@@ -1041,6 +1042,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 }
             }
             // (vm_seq stays as it is: it must remain a LOWER bound of the operations issued, and these are data dependent)
+          }
         } else if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
         } else {
@@ -2236,6 +2238,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     a.list_cap = ctx->list_cap;
     a.work = nullptr;
     a.hmode = ctx->mode == PAIR_SKL ? 1 : 0;
+    { const char *e = getenv("HSD_TOPK_DEBUG"); a.dbg = e ? atoi(e) : 0; }     // measurement: 1 = sweep without its candidate epilogue
     a.dcols_valid = (ctx->mode == PAIR_SKL) ? ctx->dcols : ctx->dcols_alg;
     a.rbase = r0;
     a.i_begin = r0; a.i_end = r1;
