@@ -736,8 +736,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         return issued;
     };
     // raw ring maxima of the granules a tile touches (lane s: segment s); consumed one tile later
-    auto issue_rmax = [&](int64_t ri0, int64_t rj0, uint32_t (&raw)[4]) __attribute__((always_inline)) {
-        raw[0] = raw[1] = raw[2] = raw[3] = 0;
+    // (a tile that does not start on a granule boundary -- a row block at any multiple of 4 -- touches three granules per side)
+    auto issue_rmax = [&](int64_t ri0, int64_t rj0, uint32_t (&raw)[6]) __attribute__((always_inline)) {
+        raw[0] = raw[1] = raw[2] = raw[3] = raw[4] = raw[5] = 0;
         if constexpr (SEG) {
             if (w == 0 && sd.rank_col0 >= 0) {
                 const uint32_t *rm = a.rmax + (int64_t)l * a.ngran;
@@ -745,15 +746,17 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 raw[1] = rm[(ri0 + BT - 1) >> 6];
                 raw[2] = rm[rj0 >> 6];
                 raw[3] = rm[(rj0 + BT - 1) >> 6];
+                raw[4] = rm[(ri0 + BT / 2) >> 6];
+                raw[5] = rm[(rj0 + BT / 2) >> 6];
             }
         }
     };
     // decide bin form / rank form per segment and write the tile's chunk list + its length into list buffer `buf`
     // (wave 0; the other waves read them behind the next barrier)
-    auto plan = [&](const uint32_t (&raw)[4], int buf) __attribute__((always_inline)) {
+    auto plan = [&](const uint32_t (&raw)[6], int buf) __attribute__((always_inline)) {
         if constexpr (SEG) {
             if (w != 0) return;
-            const uint32_t R = max(max(raw[0], raw[1]), max(raw[2], raw[3]));
+            const uint32_t R = max(max(max(raw[0], raw[1]), max(raw[2], raw[3])), max(raw[4], raw[5]));
             const int pre = plan_segment<CH, KIND == K_SAD16>(sd, l < a.n_seg, R, l, clist + buf * a.list_cap);
             if (l == 63) nlist[buf] = pre;
         }
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     int ti, tj;
     tile_from_index(a, t, ti, tj);
     int64_t i0 = uniform64(a.i_begin + (int64_t)ti * BT), j0 = uniform64(a.j_begin + (int64_t)tj * BT);
-    uint32_t raw[4];
+    uint32_t raw[6];
     issue_rmax(i0, j0, raw);
     int cur = 0;                                      // list buffer of the tile being computed
     plan(raw, cur);
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     if (has1) tile_from_index(a, t1, ti1, tj1);
     if (has2) tile_from_index(a, t2, ti2, tj2);
     int64_t i1 = uniform64(a.i_begin + (int64_t)ti1 * BT), j1 = uniform64(a.j_begin + (int64_t)tj1 * BT);
-    uint32_t raw1[4];
+    uint32_t raw1[6];
     if (has1) issue_rmax(i1, j1, raw1);
 
     int vm_seq = 0;                                   // vector-memory operations issued so far (lower bound: masked stores are not counted)
@@ -1643,8 +1646,10 @@ struct WaveList {
 // The row's own node may be among the sampled columns (its distance is an exact 0 and comes first): the (k+1)-th smallest
 // keeps tau an upper bound of the k-th nearest OTHER node whether or not it is.  Inflated: the sweep may evaluate a pair
 // from the mirrored tile, whose fp64 sums are accumulated in another order (symmetric KL).
+// slack: absolute allowance on top (symmetric KL: H_i + H_j - dots cancels, so two evaluation orders of a pair of nearly
+// identical nodes differ by ~1e-15 ABSOLUTE, which no relative inflation of a tiny distance covers).
 __global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__restrict__ S, int64_t ld, int M, int64_t row0, int64_t rows, int k,
-                                                            double *__restrict__ tau) {
+                                                            double slack, double *__restrict__ tau) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -1658,7 +1663,7 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__res
     } else {
         for (int q = 0; q <= k; ++q) wave_lex_next(sv, nullptr, M, last_v, last_i, lane, last_v, last_i);
     }
-    if (lane == 0) tau[row0 + r] = last_v + fabs(last_v) * 1e-12;
+    if (lane == 0) tau[row0 + r] = last_v + fabs(last_v) * 1e-12 + slack;
 }
 
 __global__ void fill_columns_kernel(double *__restrict__ S, int64_t ld, int64_t rows, int c_begin, int c_end, double v) {
@@ -1704,7 +1709,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const int *__restrict_
 // and takes the k-th value as its new threshold -- still an upper bound of its k-th nearest, and every later candidate
 // must beat it.  One wave per row.  Lists that overflowed are left alone (the select kernel reports them, the host retries).
 __global__ __launch_bounds__(256) void topk_compact_kernel(int *__restrict__ cnt, int *__restrict__ cidx, double *__restrict__ cval, int cap,
-                                                          int64_t rows, int k, double *__restrict__ tau) {
+                                                          int64_t rows, int k, double slack, double *__restrict__ tau) {
     extern __shared__ double cmp_sh[];                 // per wave: k values, then k indices
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double *sel_v = cmp_sh + (size_t)w * k;
@@ -1734,7 +1739,7 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(int *__restrict__ cnt
     for (int t = lane; t < k; t += 64) { cv[t] = sel_v[t]; ci[t] = sel_i[t]; }
     if (lane == 0) {
         cnt[row] = k;
-        tau[row] = fmin(tau[row], last_v + fabs(last_v) * 1e-12);   // (inflated like the first threshold: mirrored evaluation order)
+        tau[row] = fmin(tau[row], last_v + fabs(last_v) * 1e-12 + slack);   // (inflated like the first threshold: mirrored evaluation order)
     }
 }
 
@@ -2243,6 +2248,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     a.rbase = r0;
     a.i_begin = r0; a.i_end = r1;
 
+    const double slack = ctx->mode == PAIR_SKL ? 1e-11 : 0.0;      // W1 is evaluated identically in both orientations of a pair
     int64_t M = std::min<int64_t>(n, std::max<int64_t>(1024, 4 * (int64_t)k));
     // A large sweep runs in phases (anti-diagonal samples of the tile groups, tile_order): after each one every row keeps
     // its k best and tightens its threshold, so that the candidates appended per row fall from ~ k n / M to
@@ -2306,7 +2312,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
         }
         if (rc == HSD_OK && e == hipSuccess) {
             const int Ms = n_sub * 128;
-            hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, Ms, r0, rows, k, d_tau - r0);
+            hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, Ms, r0, rows, k, slack, d_tau - r0);
         }
         // 2. sweep: square on the diagonal (both rows of a pair are ours) + the blocks left and right of it
         for (int ph = 0; ph < n_phases && rc == HSD_OK && e == hipSuccess; ++ph) {
@@ -2322,7 +2328,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
             if (rc == HSD_OK && r1 < n) { b.j_begin = r1; b.j_end = n; rc = launch_region(ctx, b, BT, ctx->stream); }
             // the thresholds tighten fastest early on: compact after phases 1, 2, 4, ... (phases 5-8 of 8 together append ~k entries)
             if (rc == HSD_OK && ph + 1 < n_phases && ((ph + 1) & ph) == 0)
-                hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), (size_t)4 * k * 12, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, d_tau);
+                hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), (size_t)4 * k * 12, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, slack, d_tau);
         }
         // 3. select
         int flag[4] = {0, 0, 0, 0};

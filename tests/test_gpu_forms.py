@@ -179,3 +179,30 @@ def test_persistent_kernel_corner_shapes(engine):
             engine.pair_prepare(0, 1, 0, 3)
             out[stream] = engine.pair_rows_host()
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[0].T)
+
+
+@pytest.mark.parametrize("r0,r1", [(476, 2352), (4, 2600), (1100, 1996)])
+def test_persistent_kernel_row_block_off_the_granule_grid(engine, r0, r1):
+    """A row block that starts at a multiple of 4 but not of 64: a 128-node tile then touches THREE 64-node granules of
+    the rank-form maxima per side.  Persistent kernel (HSD_STREAM=1), zero-pad distance with rank columns (a
+    preferential-attachment graph), against the rows of the full matrix, bit for bit."""
+    from hsd_amd.graph import barabasi_albert
+    g = barabasi_albert(2675, 3, 363629067)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 1, 0, 2)
+    D = engine.pair_rows_host()
+    os.environ["HSD_STREAM"] = "1"
+    try:
+        M = engine.pair_rows_device(r0, r1)
+        block = M.to_host()
+        M.free()
+        idx, val = engine.pair_topk(9, r0, r1)
+    finally:
+        os.environ.pop("HSD_STREAM", None)
+    assert np.array_equal(block, D[r0:r1])
+    for r in (r0, (r0 + r1) // 2, r1 - 1):
+        d = D[r].copy()
+        d[r] = np.inf
+        order = np.lexsort((np.arange(g.n_node), d))[:9]
+        assert np.array_equal(order, idx[r - r0]) and np.array_equal(d[order], val[r - r0])
