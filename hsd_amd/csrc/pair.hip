@@ -1609,34 +1609,54 @@ __device__ inline void wave_lex_next(const double *__restrict__ cv, const int *_
     oi = bi;
 }
 
-// The same with the list held in registers (E entries per lane, loaded once): the rounds then cost no memory access.
+// The same with the list held in registers (E entries per lane, loaded once) as order-preserving integer keys, each lane's
+// entries SORTED (odd-even transposition, once): a round is then one comparison of the lanes' heads over six exchange steps
+// plus a shift in the winning lane, instead of E lexicographic fp64 comparisons per lane.
+__device__ inline unsigned long long topk_key(double v) {            // monotone map of the doubles onto the unsigned integers
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double topk_unkey(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
 template <int E>
 struct WaveList {
-    double v[E];
+    unsigned long long key[E];
     int i[E];
     __device__ inline void load(const double *__restrict__ cv, const int *__restrict__ ci, int c, int lane) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int t = lane + 64 * e;
-            v[e] = t < c ? cv[t] : INFINITY;
+            key[e] = t < c ? topk_key(cv[t]) : ~0ull;
             i[e] = t < c ? (ci ? ci[t] : t) : 0x7fffffff;
         }
-    }
-    __device__ inline void next(double last_v, int last_i, double &ov, int &oi) const {
-        double bv = INFINITY;
-        int bi = 0x7fffffff;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool after = v[e] > last_v || (v[e] == last_v && i[e] > last_i);
-            if (after && (v[e] < bv || (v[e] == bv && i[e] < bi))) { bv = v[e]; bi = i[e]; }
-        }
+        for (int p = 0; p < E; ++p)
+#pragma unroll
+            for (int e = p & 1; e + 1 < E; e += 2) {
+                const bool sw = key[e + 1] < key[e] || (key[e + 1] == key[e] && i[e + 1] < i[e]);
+                const unsigned long long k0 = sw ? key[e + 1] : key[e], k1 = sw ? key[e] : key[e + 1];
+                const int i0 = sw ? i[e + 1] : i[e], i1 = sw ? i[e] : i[e + 1];
+                key[e] = k0; key[e + 1] = k1; i[e] = i0; i[e + 1] = i1;
+            }
+    }
+    // the smallest entry still held by any lane; it is removed
+    __device__ inline void pop(double &ov, int &oi) {
+        unsigned long long bk = key[0];
+        int bi = i[0];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const double xv = __shfl_xor(bv, o, 64);
+            const unsigned long long xk = __shfl_xor(bk, o, 64);
             const int xi = __shfl_xor(bi, o, 64);
-            if (xv < bv || (xv == bv && xi < bi)) { bv = xv; bi = xi; }
+            if (xk < bk || (xk == bk && xi < bi)) { bk = xk; bi = xi; }
         }
-        ov = bv;
+        if (bk == key[0] && bi == i[0]) {
+#pragma unroll
+            for (int e = 0; e + 1 < E; ++e) { key[e] = key[e + 1]; i[e] = i[e + 1]; }
+            key[E - 1] = ~0ull;
+            i[E - 1] = 0x7fffffff;
+        }
+        ov = topk_unkey(bk);
         oi = bi;
     }
 };
@@ -1659,7 +1679,7 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__res
     if (M <= 1024) {
         WaveList<16> wl;
         wl.load(sv, nullptr, M, lane);
-        for (int q = 0; q <= k; ++q) wl.next(last_v, last_i, last_v, last_i);
+        for (int q = 0; q <= k; ++q) wl.pop(last_v, last_i);
     } else {
         for (int q = 0; q <= k; ++q) wave_lex_next(sv, nullptr, M, last_v, last_i, lane, last_v, last_i);
     }
@@ -1694,7 +1714,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const int *__restrict_
         WaveList<8> wl;
         wl.load(cv, ci, c, lane);
         for (int q = 0; q < k; ++q) {
-            wl.next(last_v, last_i, last_v, last_i);
+            wl.pop(last_v, last_i);
             if (lane == 0) { out_idx[lr * (int64_t)k + q] = last_i; out_val[lr * (int64_t)k + q] = last_v; }
         }
         return;
@@ -1726,7 +1746,7 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(int *__restrict__ cnt
         WaveList<8> wl;
         wl.load(cv, ci, c, lane);
         for (int q = 0; q < k; ++q) {
-            wl.next(last_v, last_i, last_v, last_i);
+            wl.pop(last_v, last_i);
             if (lane == 0) { sel_v[q] = last_v; sel_i[q] = last_i; }
         }
     } else {
