@@ -1,0 +1,57 @@
+"""dev: the Chebyshev heat-kernel path on random graphs against the numpy oracle: calculate_wavelets(approx=True)
+(thresholded psi, order 50) and MultiHSD.embed (ring [sum, mean] for several scales from one recurrence, both schedules),
+stars and hubs included (long-row chunks).  usage: python3 tools_dev/soak_heat.py [seconds=120] [seed=1]"""
+import os, sys, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import hsd_amd
+from hsd_amd.graph import Graph, barabasi_albert, erdos_renyi, connect_components
+from oracle import hsd_oracle as orc
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+eng = hsd_amd.Engine(0)
+t0, cases, worst = time.time(), 0, 0.0
+while time.time() - t0 < budget:
+    kind = int(rng.integers(0, 3))
+    n = int(rng.integers(20, 420))
+    seed = int(rng.integers(1 << 30))
+    if kind == 0: g = barabasi_albert(n, int(rng.integers(1, 5)), seed)
+    elif kind == 1: g = connect_components(erdos_renyi(n, float(rng.uniform(2, 10)) / n, seed=seed), seed)
+    else:                                            # a star with a tail: one row of n/2 entries (chunked above 128)
+        hub = np.zeros(n // 2, dtype=np.int64); leaves = np.arange(1, n // 2 + 1); path = np.arange(n // 2, n - 1)
+        g = Graph.from_edges(list(range(n)), np.concatenate([hub, path]), np.concatenate([leaves, path + 1]))
+    n = g.n_node
+    hop = int(rng.integers(1, 4))
+    A = np.zeros((n, n)); rows = np.repeat(np.arange(n), np.diff(g.rowptr)); A[rows, g.col] = 1.0
+    Lap = np.diag(A.sum(1)) - A
+    m = hsd_amd.MultiHSD(g, "soak", hop, int(rng.integers(2, 6)), engine=eng)
+    rings = orc.khop_rings(g.rowptr, g.col, hop)
+    # one scale through HSD.calculate_wavelets
+    h = hsd_amd.HSD(g, "soak", 0, hop, "wasserstein", engine=eng)
+    s = float(np.exp(rng.uniform(np.log(0.01), np.log(3.0))))
+    psi = h.calculate_wavelets(s, approx=True)
+    ref = orc.heat_wavelets_cheby(Lap, s, h.lmax, 50)
+    # entries within rounding of the threshold may fall on either side of it
+    thr = 1e-4 / n
+    near = np.abs(orc.cheby_heat_apply(Lap, orc.cheby_coeff_heat(s, h.lmax, 50), h.lmax, np.eye(n)).T - thr) < 1e-13
+    err = np.abs(psi - ref)[~near].max()
+    worst = max(worst, err)
+    if err > 1e-10:
+        print("MISMATCH wavelets", dict(kind=kind, n=n, seed=seed, scale=s, err=float(err)), flush=True); sys.exit(1)
+    # all scales of MultiHSD from one recurrence, both schedules
+    for sched in ("1", "0"):
+        os.environ["HSD_CHEBY_STORE"] = sched
+        try: emb = m.embed(approx=True)
+        finally: os.environ.pop("HSD_CHEBY_STORE", None)
+        E = np.asarray([emb[v] for v in m.nodes]).reshape(n, len(m.scales), hop + 1, 2)
+        for si, sc in enumerate(m.scales):
+            P = orc.heat_wavelets_cheby(Lap, float(sc), m.lmax, 50)
+            for i in rng.integers(0, n, 6):
+                want = np.asarray(orc.get_triple(P, rings[i], i)).reshape(hop + 1, 2)
+                e2 = np.abs(E[i, si] - want).max()
+                worst = max(worst, e2)
+                if e2 > 1e-9:
+                    print("MISMATCH embed", dict(kind=kind, n=n, seed=seed, sched=sched, scale=float(sc), node=int(i), err=float(e2)), flush=True); sys.exit(1)
+    cases += 1
+print(f"soak_heat: {cases} graphs, wavelets and multi-scale ring statistics match the oracle (worst abs difference {worst:.2e}) in {time.time() - t0:.0f} s", flush=True)
