@@ -1884,8 +1884,8 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         const int bin_words = pack ? (V + 1) / 2 : B;
         const int bin_stride = (int)round_up(bin_words, CH);
 
-        // Threshold and rank columns per layer.  Candidates: theta = 0 (pure rank form) and the bin boundaries that fall on a
-        // word boundary of the packed bin columns nearest to eighths of the support.  For each, the members above theta of
+        // Threshold and rank columns per layer.  Candidates: theta = 0 (pure rank form), the bin boundaries that fall on a
+        // word boundary of the packed bin columns nearest to eighths of the support, and bins 2 / 4 / 8 / 16.  For each, the members above theta of
         // every node -> maxima per 64-node granule -> expected words per tile pair
         //   low words + E[ rank words if they fit the cap, else the upper bin words ]
         // over all granule pairs (exact from the sorted maxima); the cheapest candidate is stored, or none if nothing
@@ -1901,12 +1901,17 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         else for (int r = 0; r <= B; ++r) vfirst[(size_t)r] = r;
         std::vector<int> cand;                                  // raw column index r*: columns [0, r*) stay in bin form
         cand.push_back(0);
-        if (rank_mode >= 2)
-            for (int e8 = 1; e8 < 8; ++e8) {
-                int r = std::max(1, e8 * B / 8);
+        if (rank_mode >= 2) {
+            // ... and a few cuts close to the bottom of the support: a ring of ~10 members (ring 1 of a scale-free graph)
+            // is cheapest with its two or three most common small values in bin form and the rest by rank
+            std::vector<int> wanted = {2, 4, 8, 16};
+            for (int e8 = 1; e8 < 8; ++e8) wanted.push_back(std::max(1, e8 * B / 8));
+            std::sort(wanted.begin(), wanted.end());
+            for (int r : wanted) {
                 while (r < B && pack && (vfirst[(size_t)r] & 1)) ++r;     // packed: the cut must fall between two words
                 if (r < B && r > cand.back()) cand.push_back(r);
             }
+        }
         const int NC = (int)cand.size();
         std::vector<uint32_t> gmax;                             // [nl_hist][NC][ngran]
         if (rank_ok) {
