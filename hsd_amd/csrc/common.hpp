@@ -35,7 +35,10 @@ constexpr int HSD_LCHUNK = 64;     // CSR entries per chunk of a long Laplacian 
 // One layer of a zero-pad distance (csrc/pair.hip, SegDesc): its bin-form columns [bin_col0, +bin_words), and -- where
 // it pays -- a second column range [rank_col0, ...) holding a copy of the bin columns below the layer's threshold
 // (rank_low words) followed by the rank columns of the members above it (at most rank_cap words).  rank_col0 < 0: none.
-struct HsdSegDesc { int bin_col0, bin_words, rank_col0, rank_low, rank_cap; };
+// suf_row0 >= 0: rows [suf_row0, suf_row0 + rank_cap] of the suffix matrix hold, for word index w, the sum of the layer's rank
+// values from word w on (persistent kernel, "min form": a tile pair reads only as many rank words as the SHORTER of its two
+// sides needs and takes the rest of the longer side from this sum).
+struct HsdSegDesc { int bin_col0, bin_words, rank_col0, rank_low, rank_cap, suf_row0; };
 
 struct hsd_ctx {
     int device = 0;
@@ -91,6 +94,16 @@ struct hsd_ctx {
     HsdSegDesc *d_seg_tab = nullptr;
     uint32_t *d_rmax = nullptr;        // zero-pad rank form: largest ring per layer and 64-node granule [n_seg][ngran]
     int ngran = 0;
+    // Tile composition of the persistent pair kernel: a tile side is EIGHT 16-node granules (16 fp64 = one 128-byte line of the
+    // matrix) named by a granule list; the list of the whole graph is sorted by a rank-form key chosen by hsd_pair_prepare
+    // (homogeneous tiles need fewer rank words) or is the natural order.  Lists of row / column ranges are cut out of it.
+    uint32_t *d_rmax16 = nullptr;      // members above the layer's threshold, maximum per 16-node granule [n_seg][ngran16]
+    int ngran16 = 0;
+    std::vector<int32_t> gran_order;   // granules of the nodes [0, n - n % 128) in tile order (empty: natural order)
+    uint32_t *d_suf = nullptr;         // suffix sums of the rank columns [suf_rows][npad] (row 0: zeros)
+    int suf_rows = 0;
+    struct GranList { int64_t begin, end; int32_t *d_gl; uint32_t *d_tmax; int ntiles; };
+    std::vector<GranList> gran_lists;
     int list_cap = 0;                  // entries of the pair kernel's per-tile chunk list (LDS)
     int *d_tile_ctr = nullptr;         // persistent pair kernel: 4 sets of 8 per-XCD tile counters
     unsigned long long *d_work = nullptr;   // operand words x pairs evaluated by the last hsd_pair_rows (hsd_pair_work)
@@ -142,6 +155,8 @@ struct hsd_ctx {
 };
 
 int hsd_fail(hsd_ctx *ctx, int status, const char *fmt, ...);
+// internal status (never crosses the ABI): the bit-parallel k-hop sweep could not allocate its planes
+constexpr int HSD_INT_NO_PLANES = -1000;
 
 #define HSD_HIP(ctx, call)                                                                   \
     do {                                                                                     \

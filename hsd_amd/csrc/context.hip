@@ -69,6 +69,12 @@ void hsd_release_operands(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_inv);
     hsd_dev_free(ctx->d_seg_tab);
     hsd_dev_free(ctx->d_rmax);
+    hsd_dev_free(ctx->d_rmax16);
+    hsd_dev_free(ctx->d_suf);
+    for (auto &g : ctx->gran_lists) { (void)hipFree(g.d_gl); (void)hipFree(g.d_tmax); }
+    ctx->gran_lists.clear();
+    ctx->gran_order.clear();
+    ctx->suf_rows = 0;
     ctx->mode = PAIR_NONE;
 }
 
@@ -242,30 +248,86 @@ __device__ inline double wave_min(double v) {
     return v;
 }
 
-// one workgroup per row; partial[row*5 + q]
+// Tile-wise: a workgroup owns a strip of 64 rows and a group of MS_GROUP column tiles (64 columns each).  Inside the
+// block's square part (columns [row0, row0 + rows): the entries whose mirror image is also in the block) the tile
+// (ti, tj), tj > ti, is handled together with its mirror (tj, ti) -- both are read row-wise (coalesced), the mirror is
+// transposed through LDS -- so every entry is read exactly ONCE: an 80 GB matrix costs 80 GB of reads (the round-2 kernel
+// walked the mirror as a column, 8 bytes out of every line: 967 GB).  partial[(strip * groups + group) * 5 + q].
+constexpr int MS_TILE = 64, MS_GROUP = 16;
 __global__ __launch_bounds__(256) void matrix_stats_kernel(const double *__restrict__ D, int64_t rows, int64_t cols,
-                                                          int64_t ld, int64_t row0, double *__restrict__ partial) {
+                                                          int64_t ld, int64_t row0, int64_t sq_tiles, int64_t side_tiles_left,
+                                                          int64_t side_tiles, int groups, double *__restrict__ partial) {
+    __shared__ double tr[MS_TILE][MS_TILE + 1];
     __shared__ double red[4][5];
-    const int64_t r = blockIdx.x;
-    const double *row = D + r * ld;
-    double s = 0.0, mx = -INFINITY, mn = INFINITY, asym = 0.0;
-    for (int64_t j = threadIdx.x; j < cols; j += 256) {
-        const double v = row[j];
-        s += v;
-        mx = fmax(mx, v);
-        mn = fmin(mn, v);
-        const int64_t jr = j - row0;          // row index of the mirrored entry inside this block
-        if (jr >= 0 && jr < rows) asym = fmax(asym, fabs(v - D[jr * ld + (row0 + r)]));
+    const int64_t ti = blockIdx.x;
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6;      // thread: column c, rows rq, rq + 4, ...
+    double s = 0.0, mx = -INFINITY, mn = INFINITY, asym = 0.0, diag = 0.0;
+    const int64_t i_lo = ti * MS_TILE;
+    // column tiles are numbered: [0, side_tiles_left) left of the square, then the sq_tiles tiles of the square (aligned
+    // with the row strips), then the tiles right of it
+    const int64_t total = side_tiles + sq_tiles;
+    const int64_t t_end = total < (int64_t)(blockIdx.y + 1) * MS_GROUP ? total : (int64_t)(blockIdx.y + 1) * MS_GROUP;
+    for (int64_t t = (int64_t)blockIdx.y * MS_GROUP; t < t_end; ++t) {
+        int64_t j_lo, j_hi;
+        bool square = false;
+        if (t < side_tiles_left) { j_lo = t * MS_TILE; j_hi = row0 < j_lo + MS_TILE ? row0 : j_lo + MS_TILE; }
+        else if (t < side_tiles_left + sq_tiles) {
+            const int64_t tj = t - side_tiles_left;
+            if (tj < ti) continue;                                  // read by the strip that owns its mirror
+            square = true;
+            j_lo = row0 + tj * MS_TILE; j_hi = row0 + rows < j_lo + MS_TILE ? row0 + rows : j_lo + MS_TILE;
+        } else {
+            j_lo = row0 + rows + (t - side_tiles_left - sq_tiles) * MS_TILE; j_hi = cols < j_lo + MS_TILE ? cols : j_lo + MS_TILE;
+        }
+        const int64_t tj = square ? t - side_tiles_left : -1;
+        const bool mirror = square && tj > ti;
+        if (mirror) {
+            // the mirror tile: rows tj*64.., columns row0 + ti*64..; tr[r][c] = D[tj*64 + r][row0 + ti*64 + c]
+            __syncthreads();
+            for (int r = rq; r < MS_TILE; r += 4) {
+                const int64_t i = tj * MS_TILE + r, j = row0 + i_lo + c;
+                double v = 0.0;
+                const bool ok = i < rows && j < row0 + rows;
+                if (ok) {
+                    v = D[i * ld + j];
+                    s += v; mx = fmax(mx, v); mn = fmin(mn, v);
+                }
+                tr[r][c] = v;
+            }
+            __syncthreads();
+        }
+        for (int r = rq; r < MS_TILE; r += 4) {
+            const int64_t i = i_lo + r, j = j_lo + c;
+            if (i >= rows || j >= j_hi) continue;
+            const double v = D[i * ld + j];
+            s += v; mx = fmax(mx, v); mn = fmin(mn, v);
+            if (square) {
+                if (j == row0 + i) diag = fmax(diag, fabs(v));
+                if (mirror) asym = fmax(asym, fabs(v - tr[c][r]));
+            }
+        }
+        if (square && !mirror) {
+            // a tile on the diagonal is its own mirror: transpose it through LDS as well
+            __syncthreads();
+            for (int r = rq; r < MS_TILE; r += 4) {
+                const int64_t i = i_lo + r, j = j_lo + c;
+                tr[r][c] = (i < rows && j < j_hi) ? D[i * ld + j] : 0.0;
+            }
+            __syncthreads();
+            for (int r = rq; r < MS_TILE; r += 4) {
+                const int64_t i = i_lo + r, j = j_lo + c;
+                if (i < rows && j < j_hi && c > r) asym = fmax(asym, fabs(tr[r][c] - tr[c][r]));
+            }
+        }
     }
-    double diag = (row0 + r < cols) ? fabs(row[row0 + r]) : 0.0;
-    s = wave_sum(s); mx = wave_max(mx); mn = wave_min(mn); asym = wave_max(asym);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[w][0] = s; red[w][1] = diag; red[w][2] = asym; red[w][3] = mx; red[w][4] = mn; }
+    s = wave_sum(s); mx = wave_max(mx); mn = wave_min(mn); asym = wave_max(asym); diag = wave_max(diag);
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) { red[w][0] = s; red[w][1] = diag; red[w][2] = asym; red[w][3] = mx; red[w][4] = mn; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double *p = partial + r * 5;
+    if (tid == 0) {
+        double *p = partial + ((int64_t)blockIdx.x * groups + blockIdx.y) * 5;
         p[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        p[1] = red[0][1];
+        p[1] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
         p[2] = fmax(fmax(red[0][2], red[1][2]), fmax(red[2][2], red[3][2]));
         p[3] = fmax(fmax(red[0][3], red[1][3]), fmax(red[2][3], red[3][3]));
         p[4] = fmin(fmin(red[0][4], red[1][4]), fmin(red[2][4], red[3][4]));
@@ -275,27 +337,36 @@ __global__ __launch_bounds__(256) void matrix_stats_kernel(const double *__restr
 extern "C" int hsd_matrix_stats(hsd_ctx *ctx, const double *dev_block, int64_t rows, int64_t cols, int64_t ld,
                                 int64_t row0, double *stats) {
     HSD_CHECK_CTX(ctx);
-    if (!dev_block || !stats || rows <= 0 || cols <= 0 || ld < cols)
+    if (!dev_block || !stats || rows <= 0 || cols <= 0 || ld < cols || row0 < 0)
         return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_matrix_stats: bad arguments");
+    // the square part: columns [row0, row0 + rows) clipped to the matrix
+    const int64_t sq = std::max<int64_t>(0, std::min<int64_t>(rows, cols - row0));
+    if (sq < rows && row0 < cols) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_matrix_stats: the block's square part is cut by the last column");
+    const int64_t left = std::min<int64_t>(row0, cols), right = std::max<int64_t>(0, cols - row0 - sq);
+    const int64_t tl = (left + MS_TILE - 1) / MS_TILE, trr = (right + MS_TILE - 1) / MS_TILE, ts = (sq + MS_TILE - 1) / MS_TILE;
+    const int64_t strips = (rows + MS_TILE - 1) / MS_TILE;
+    const int groups = (int)((tl + ts + trr + MS_GROUP - 1) / MS_GROUP);
+    if (groups > 65535) return hsd_fail(ctx, HSD_ERR_TOO_LARGE, "hsd_matrix_stats: too many column tiles");
     double *d_part = nullptr;
-    int rc = hsd_dev_alloc(ctx, &d_part, (size_t)rows * 5);
+    const size_t np = (size_t)strips * groups;
+    int rc = hsd_dev_alloc(ctx, &d_part, np * 5);
     if (rc) return rc;
-    hipLaunchKernelGGL(matrix_stats_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, dev_block, rows, cols, ld,
-                       row0, d_part);
-    std::vector<double> part((size_t)rows * 5);
+    hipLaunchKernelGGL(matrix_stats_kernel, dim3((unsigned)strips, (unsigned)groups), dim3(256), 0, ctx->stream, dev_block, rows, cols, ld,
+                       row0, ts, tl, tl + trr, groups, d_part);
+    std::vector<double> part(np * 5);
     hipError_t e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_part);
     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "hsd_matrix_stats: %s", hipGetErrorString(e));
-    // pairwise-ish: sum row sums in long double for a stable checksum
+    // partial sums added in long double, in a fixed order: a stable checksum
     long double s = 0.0L;
     double diag = 0.0, asym = 0.0, mx = -INFINITY, mn = INFINITY;
-    for (int64_t r = 0; r < rows; ++r) {
-        s += part[(size_t)r * 5];
-        diag = std::max(diag, part[(size_t)r * 5 + 1]);
-        asym = std::max(asym, part[(size_t)r * 5 + 2]);
-        mx = std::max(mx, part[(size_t)r * 5 + 3]);
-        mn = std::min(mn, part[(size_t)r * 5 + 4]);
+    for (size_t r = 0; r < np; ++r) {
+        s += part[r * 5];
+        diag = std::max(diag, part[r * 5 + 1]);
+        asym = std::max(asym, part[r * 5 + 2]);
+        mx = std::max(mx, part[r * 5 + 3]);
+        mn = std::min(mn, part[r * 5 + 4]);
     }
     stats[0] = (double)s; stats[1] = diag; stats[2] = asym; stats[3] = mx; stats[4] = mn;
     return HSD_OK;

@@ -170,26 +170,32 @@ hipError_t launch_g(hsd_ctx *ctx, int grid, size_t lds_bytes, int hop, int64_t r
 int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, int32_t *d_sizes, const int64_t *d_offsets,
                     int32_t *d_members) {
     const int64_t n = ctx->n;
-    // histograms only: the bit-parallel sweep of 4096 sources at a time (khop_ms.hip) once the graph is large enough to
-    // fill its planes; HSD_KHOP_MS=0 / 1 forces the per-source sweep / the bit-parallel one
-    const char *em_ = getenv("HSD_KHOP_MS");
-    const bool ms_wanted = em_ ? atoi(em_) != 0 : (n >= 8192 && hop >= 2 && r1 - r0 >= 2048);
-    if (!hist && d_sizes && !d_members && ms_wanted && r1 > r0) {
+    // histograms / ring sizes only: the bit-parallel sweep of 4096 sources at a time (khop_ms.hip) once the graph is large
+    // enough to fill its planes (a batch costs the same for one source as for 4096: short source ranges stay with the
+    // per-source sweep); HSD_KHOP_MS=0 / 1 forces the per-source sweep / the bit-parallel one.  The bit-parallel sweep needs
+    // 3 n x 512 B of planes + 2 (hop - 1) n x 512 B of ring planes: if they cannot be allocated (a large graph next to its
+    // own [n][hop + 1][bins] histogram tensor) the per-source sweep below, which needs LDS bitmaps only, takes over.
+    const auto ms_wanted = [&]() {
+        if (const char *em = getenv("HSD_KHOP_MS")) return atoi(em) != 0;
+        return n >= 8192 && hop >= 2 && r1 - r0 >= 2048;
+    };
+    if (!hist && d_sizes && !d_members && r1 > r0 && ms_wanted()) {
         // ring sizes alone (hsd_khop_sizes: hierarchical degree, SIR labels): the bit-parallel sweep over ONE bin counts them
         int32_t *d_zero = nullptr;
         int rc = hsd_dev_alloc(ctx, &d_zero, (size_t)n);
-        if (rc) return rc;
-        hipError_t e = hipMemsetAsync(d_zero, 0, (size_t)n * sizeof(int32_t), ctx->stream);
-        if (e == hipSuccess) rc = hsd_launch_khop_ms(ctx, hop, r0, r1, reinterpret_cast<uint32_t *>(d_sizes) - r0 * (hop + 1), d_zero, 1);
-        const hipError_t e2 = hipStreamSynchronize(ctx->stream);          // d_zero is read until the sweep has finished
-        hsd_dev_free(d_zero);
-        if (e != hipSuccess || e2 != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "khop sizes: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-        return rc;
-    }
-    if (hist && !d_sizes && !d_members && hsd_khop_ms_usable(ctx, hop, ctx->n_bins)) {
-        const char *em = getenv("HSD_KHOP_MS");
-        // (a batch costs the same for one source as for 4096: short source ranges stay with the per-source sweep)
-        if (em ? atoi(em) != 0 : (n >= 8192 && hop >= 2 && r1 - r0 >= 2048)) return hsd_launch_khop_ms(ctx, hop, r0, r1);
+        if (rc == HSD_OK) {
+            hipError_t e = hipMemsetAsync(d_zero, 0, (size_t)n * sizeof(int32_t), ctx->stream);
+            if (e == hipSuccess) rc = hsd_launch_khop_ms(ctx, hop, r0, r1, reinterpret_cast<uint32_t *>(d_sizes) - r0 * (hop + 1), d_zero, 1);
+            const hipError_t e2 = hipStreamSynchronize(ctx->stream);          // d_zero is read until the sweep has finished
+            hsd_dev_free(d_zero);
+            if (e != hipSuccess || e2 != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "khop sizes: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        if (rc != HSD_INT_NO_PLANES) return rc;
+        (void)hipGetLastError();                          // planes did not fit: per-source sweep
+    } else if (hist && !d_sizes && !d_members && hsd_khop_ms_usable(ctx, hop, ctx->n_bins) && ms_wanted()) {
+        const int rc = hsd_launch_khop_ms(ctx, hop, r0, r1);
+        if (rc != HSD_INT_NO_PLANES) return rc;
+        (void)hipGetLastError();
     }
     const int words = (int)((n + 31) / 32);
     const int n_hist = hist ? (hop + 1) * ctx->n_bins : 0;

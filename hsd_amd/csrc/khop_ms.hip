@@ -309,7 +309,14 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, uint32_t *
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hsd_dev_free(ctx->d_ms_planes);
         ctx->ms_plane_words = 0;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_ms_planes, words))) return rc;
+        // (no room for the planes: the caller falls back to the per-source sweep, which needs LDS bitmaps only;
+        // HSD_KHOP_MS_NOPLANES=1 rehearses that in the tests)
+        if (getenv("HSD_KHOP_MS_NOPLANES")) return HSD_INT_NO_PLANES;
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_ms_planes), words * sizeof(*ctx->d_ms_planes)) != hipSuccess) {
+            ctx->d_ms_planes = nullptr;
+            (void)hipGetLastError();
+            return HSD_INT_NO_PLANES;
+        }
         ctx->ms_plane_words = words;
     }
     if (overlap && !ctx->ms_stream) {

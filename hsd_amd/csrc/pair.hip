@@ -31,6 +31,9 @@ namespace {
 #ifndef HSD_PIN
 #define HSD_PIN 1
 #endif
+#ifndef HSD_STAMPS
+#define HSD_STAMPS 0                // 1: the persistent kernel carries its in-kernel cycle stamps (HSD_DEBUG bit 3) and the plain-store switch
+#endif                              //    (bit 2) -- a measurement build: a dozen scalar registers the product kernel needs for itself
 #ifndef HSD_F64_UNROLL
 #define HSD_F64_UNROLL 4            // columns per straight-line trip of the fp64 inner loops (2 = the plain two-column loop)
 #endif
@@ -77,6 +80,12 @@ struct PairArgs {
     int dbg;                // HSD_DEBUG ablation bits: 1 = no stores, 2 = no arithmetic
     // fused k-nearest consumer (hsd_pair_topk): instead of storing the tile, every value below its
     // row's threshold tau is appended to that row's candidate list
+    // persistent kernel: tile composition (eight 16-node granules per tile side) and the min form of rank segments
+    const int32_t *gl_i, *gl_j;     // granule lists of the region's row / column range, 8 entries per list tile
+    const uint32_t *tmax_i, *tmax_j;   // [n_seg][ntl]: most members above the segment's threshold among a list tile's nodes
+    int ntl_i, ntl_j;               // list tiles per side (row stride of tmax)
+    const uint32_t *suf;            // suffix sums of the rank columns [rows][npad] (HsdSegDesc::suf_row0)
+    unsigned long long *stamps;     // HSD_DEBUG bit 3: per-workgroup lifetimes (measurement), else nullptr
     const double *tau;      // [n] per-node threshold, or nullptr for the normal matrix output
     int *cand_cnt;          // [n] candidates appended so far (may exceed cand_cap: overflow)
     int *cand_idx;          // [n][cand_cap]
@@ -155,6 +164,19 @@ __device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_
     // (M0 is a reserved register: hipcc does not accept it as a clobber.  Nothing else in pair_stream_kernel uses M0 -- DS
     // instructions do not on gfx9+, and the kernel contains no LDS-DMA builtin, s_movrel or message instruction.)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
+}
+
+// A 16-byte store per lane with a scalar 64-bit base and a 32-bit per-lane offset, non-temporal or plain.  (Written out:
+// the result stores of the persistent kernel then cost no vector address arithmetic.  hipcc does not count them in its own
+// vmcnt bookkeeping, like the loads above: whatever it waits for with a counted vmcnt is older than these by program order.)
+// The s_nop is part of the contract: a store of more than 64 bits followed within two wait states (gfx940+) by a vector
+// write to its data registers is a hazard the hardware does not interlock.  hipcc pads its own stores; it cannot see into
+// this one, and it does re-use the four registers it copies a non-adjacent accumulator pair into for the next store
+// (measured without the pad: one mirrored entry in ~10^5 carried its neighbour's value).
+template <bool NT>
+__device__ inline void gstore16_s(uint64_t sbase, uint32_t lane_off, v2f64 val) {
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
 }
 
 // Stage CH columns x BT nodes of one operand: LDS image [CH][BT] of T (linear, as in memory).
@@ -608,26 +630,34 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
 }
 
 // ------------------------------------------------------------------------------------------
-// pair_stream_kernel<KIND, NW>: the same arithmetic as a PERSISTENT workgroup that streams through its tiles.
-//   NW = 4: 128 x 128 tiles as above (wave w owns quadrant (w >> 1, w & 1)), one barrier per operand chunk -- the only
-//           instantiation that is built;
-//   NW = 1: ONE WAVE per workgroup and NO barriers (64 x 64 tiles) -- what the kernel started as (next paragraph); it
-//           stages twice the operand bytes per pair and measured 247 vs 219 ms (raw fp64 W1) / 31 vs 29 ms (zero-pad) at
-//           BA N = 100k, so it is no longer instantiated; the NW == 1 branches are kept as the record of that design.
+// pair_stream_kernel<KIND, 4>: the same arithmetic as a PERSISTENT workgroup that streams through its tiles
+// (128 x 128 tiles, wave w owns quadrant (w >> 1, w & 1), one barrier per operand chunk).
 //
-// Measured on the 4-wave kernel above at BA N = 100k (profiles/r02a_*): with the zero-pad distance down to ~137 words
+// Measured on the one-tile kernel above at BA N = 100k (profiles/r02a_*): with the zero-pad distance down to ~137 words
 // per pair the waves sat in s_waitcnt / s_barrier for 29 % of their cycles and the vector ALU was busy 62 % of the
-// time even with stores disabled -- a wave alone on its SIMD issues one v_sad every ~8.7 cycles against 4.1 when two
-// interleave (tools_dev/ubench_valu.hip), so every stall of one workgroup (tile prologue, per-chunk barrier skew,
-// epilogue) halves the other's rate.  Here a wave owns a whole 64 x 64 tile (8 x 8 pairs per lane, the quadrant of the
-// kernel above), stages its own operand chunks (2-stage ring, one chunk ahead; two ahead across a tile boundary so the
-// epilogue's stores are issued behind the next tile's first loads) and walks a strided share of its XCD's tile run:
-// nothing ever waits for another wave, and the next tile's plan (coordinates, rank-form decision, chunk list) is
-// resolved one tile ahead.  Results are bit-identical to the kernel above (same per-pair operation order).
+// time even with stores disabled: every stall of one workgroup (tile prologue, per-chunk barrier skew, epilogue) leaves the
+// SIMD to the one other wave.  Here 512 workgroups stay resident, the next tile's plan (coordinates, form decision, chunk
+// list) is resolved one tile ahead by wave 0, and its first operand chunks are requested before the current tile's stores.
+// (A one-wave, barrier-free 64 x 64 variant and an eight-wave 8 x 4-pairs-per-lane variant were built and measured:
+// 247 vs 219 ms / 31 vs 29 ms, and 1052 vs 226 ms / 26.2 vs 22.3 ms -- profiles/r03_exp_nw8_defer_ab.txt -- both dropped.)
+//
+// Round 3 -- TILE COMPOSITION.  A tile side is no longer 128 consecutive nodes but EIGHT 16-NODE GRANULES named by a granule
+// list (PairArgs::gl_i / gl_j, eight entries per list tile).  16 nodes are 16 fp64 = one 128-byte line of a matrix row, so the
+// kernel's stores keep their shape (every 8-lane group writes one whole line) whatever granules make up a tile; the operand
+// loads take a per-lane offset (a granule's slice of one column is 64 B of uint32 / 128 B of fp64, the direct-to-LDS
+// instruction has per-lane addresses anyway).  hsd_pair_prepare sorts the list by the layers' rank-form key, so that the
+// nodes of a tile need about the same number of rank words (BA N = 100k, Variant B: 99 -> ~66 words per pair together with
+// the min form below); the natural list reproduces round 2's tiles.  Results do not depend on the composition: every pair
+// is evaluated by the same operations in the same order, whichever tile it lands in.
+//
+// Round 3 -- MIN FORM of a rank segment.  Rank columns hold a node's member values above the layer's threshold in descending
+// order, zeros beyond its own count.  With R_I / R_J the largest counts on the two sides of a tile pair, every node of the
+// SHORTER side is zero from rank min(R_I, R_J) on, so beyond that point |u_i(r) - u_j(r)| is just the longer side's own value:
+// the tile reads only ceil(min(R_I, R_J) / 2) rank words and adds the longer side's precomputed suffix sum
+// (HsdSegDesc::suf_row0: one uint32 per node and word index) to the integer accumulator before the layer's fold.  The same
+// integer as the bin form and the max form (tests/test_gpu_forms.py compares them bit for bit).
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int stream_chunk_cols(int kind, int nw) {
-    return nw == 1 ? ((kind == K_SAD || kind == K_SAD16) ? 16 : 8) : chunk_cols(kind);
-}
+__host__ __device__ constexpr int stream_chunk_cols(int kind) { return chunk_cols(kind); }
 
 // wait until at most `young` of this wave's vector-memory operations are outstanding (they retire in order, so that
 // means everything older than the `young` newest has landed); a smaller count than the true one only waits longer
@@ -640,41 +670,88 @@ __device__ inline void wait_vm_young(int young) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Lane l < n_seg holds segment l.  RI / RJ: most members above the segment's threshold among the nodes of the tile's two
+// sides.  Chooses bin form or (min form) rank form, appends the segment's chunks to the tile's list like plan_segment and
+// leaves in smeta[l] the suffix row to add and the side it belongs to (bit 30: the J side), or -1.
+template <int CH, bool PACK>
+__device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t RI, uint32_t RJ, int l, int2 *lst, int *smeta) {
+    int col0 = sd.bin_col0, words = active ? sd.bin_words : 0, sm = -1;
+    if (active && sd.rank_col0 >= 0 && sd.suf_row0 >= 0) {
+        const uint32_t Rm = min(RI, RJ);
+        int wr = PACK ? (int)((Rm + 1) >> 1) : (int)Rm;
+        if (sd.rank_low + wr == 0 && sd.rank_cap >= 1) wr = 1;      // a layer always closes with a fold (the longer side's suffix is added there)
+        if (wr <= sd.rank_cap) {
+            col0 = sd.rank_col0;
+            words = sd.rank_low + wr;
+            sm = (sd.suf_row0 + wr) | (RI >= RJ ? 0 : (1 << 30));
+        }
+    }
+    if (l < 4) smeta[l] = sm;
+    const int nch = (words + CH - 1) / CH;
+    int pre = nch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(pre, o, 64);
+        if (l >= o) pre += up;
+    }
+    int2 *dst = lst + (pre - nch);
+    for (int c = 0; c < nch; ++c)
+        dst[c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+    return pre;
+}
+
 // TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
 // candidate list instead of being stored (a separate instantiation: the matrix kernels' code is not touched by it).
 template <int KIND, int NW, bool TOPK = false>
 __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs a) {
     using T = typename Elem<KIND>::type;
     using T2 = typename Vec2<T>::type;
-    constexpr int TR = 8, TC = 8, BT = NW == 4 ? 128 : 64;
+    constexpr int TR = 8, TC = 8, BT = 128;
     constexpr bool SEG = (KIND == K_SAD || KIND == K_ZP || KIND == K_SAD16);
-    constexpr int CH = stream_chunk_cols(KIND, NW);
+    constexpr bool U32 = sizeof(T) == 4;
+    constexpr int CH = stream_chunk_cols(KIND);
     constexpr int STAGE = 2 * CH * BT;               // elements per stage: I block, then J block
-    static_assert(NW == 1 || NW == 4, "one wave (64 x 64 tile) or four (128 x 128)");
+    static_assert(NW == 4, "four waves per 128 x 128 tile");
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     T *sbase = reinterpret_cast<T *>(lds_raw);
     int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
     int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths; [2]: the tile index drawn for the tile after next
+    // [3][24] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side) and, per layer
+    // segment, the most members above its threshold on the I side (16-19) and on the J side (20-23)
+    int *meta = nlist + 4;
+    constexpr int META = 24;
+    int *smeta = meta + 3 * META;                    // [2][4]: per layer segment, suffix row | side << 30, or -1
+    SegDesc *segd = reinterpret_cast<SegDesc *>(smeta + 8);      // [4]
     // auxiliary per-node vectors of the current and the next tile: [2 tiles][n_aux][I: 128 doubles | J: 128 doubles]
     // (vector v < n_seg: 1/ring size of layer v; then the ring-0 value or the entropy term)
-    double *aux = reinterpret_cast<double *>(nlist + 4);
+    double *aux = reinterpret_cast<double *>(segd + 4);          // (4 x 24 bytes: still 16-byte aligned)
     constexpr int AUX_STRIDE = 256;                  // doubles per vector: one 1-KiB direct-to-LDS instruction per side
+    // suffix sums of the longer side of a rank segment: [2 tiles][n_seg][128 uint32]
+    uint32_t *sufb = reinterpret_cast<uint32_t *>(aux + 2 * a.n_aux * AUX_STRIDE);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double *)lds_raw);
+    auto lds_off = [&](const void *p) __attribute__((always_inline)) -> uint32_t {
+        return lds_base + (uint32_t)(reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(lds_raw));
+    };
 
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), l = threadIdx.x & 63;
     const int ly = l >> 3, lx = l & 7;
-    const int wi = (NW == 4 ? (w >> 1) * 64 : 0) + 2 * ly, wj = (NW == 4 ? (w & 1) * 64 : 0) + 2 * lx;
+    const int wi = (w >> 1) * 64 + 2 * ly, wj = (w & 1) * 64 + 2 * lx;
+    // The lane id as the compiler cannot see through: everything derived from it at a point of use (LDS addresses of the
+    // per-tile tables and vectors, request offsets, store offsets) is then formed there, instead of being hoisted out of the
+    // tile loop into one more register that lives across the inner loop -- there are two dozen such values and no registers.
+    auto lane = [&]() __attribute__((always_inline)) -> int { int v = l; asm volatile("" : "+v"(v)); return v; };
     auto wg_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
     };
     const T *__restrict__ XI = reinterpret_cast<const T *>(a.swap ? a.Y : a.X);
     const T *__restrict__ XJ = reinterpret_cast<const T *>(a.swap ? a.X : a.Y);
-    gdouble *const out = (gdouble *)a.out;
     gcdouble *const gH = (gcdouble *)a.H;
     gcdouble *const ginv = (gcdouble *)a.inv;
     gcdouble *const gpoint = (gcdouble *)a.point;
+#if HSD_STAMPS
     const bool nt = !(a.dbg & 4);
+#endif
 
     // this wave's share: XCD x (workgroups b, b + 8, ... share one) owns a contiguous run of the tile order
     const int x = blockIdx.x & 7, wx = blockIdx.x >> 3, nwx = gridDim.x >> 3;
@@ -688,32 +765,54 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     int t = lo + wx;
     if (t >= hi) return;
     int src = x;                                      // (wave 0, lane 0) the XCD whose counter this workgroup draws from; -1: all dry
+#if HSD_STAMPS
     const unsigned long long stamp0 = (a.dbg & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // HSD_DEBUG bit 3: lifetime stamps
+#endif
 
-    // lane s keeps the description of layer segment s
-    SegDesc sd{};
+    // the descriptions of the layer segments: copied to LDS once, read by the planning lanes tile by tile
     if constexpr (SEG) {
-        if (l < a.n_seg) sd = a.seg_tab[l];
-        else sd.rank_col0 = -1;
+        if (w == 0 && l < 4) {
+            SegDesc d{};
+            d.rank_col0 = -1; d.suf_row0 = -1;
+            if (l < a.n_seg) d = a.seg_tab[l];
+            segd[l] = d;
+        }
     }
-    // requests the first `valid` columns of a chunk (the tail of a layer's last chunk is not fetched); returns the number of
-    // direct-to-LDS instructions THIS wave issued
-    auto stage_chunk = [&](int col, int valid, int64_t ri0, int64_t rj0, int st) __attribute__((always_inline)) -> int {
+    // Per-lane byte offsets of a tile's operand requests, from its granules (ring slot `ms`): this lane's granule of the I / J
+    // side within a column slice (uint32 kinds: two columns per instruction, 4 lanes = 64 B per granule; fp64: one column,
+    // 8 lanes = 128 B per granule).  Recomputed per request (two LDS reads): held across the tile they cost four registers
+    // of a kernel that has none to spare.
+    auto operand_offsets = [&](int ms, uint32_t &oI, uint32_t &oJ) __attribute__((always_inline)) {
+        const int *g = meta + ms * META;
+        const int lv = lane();
+        if constexpr (U32) {
+            const uint32_t colpart = (uint32_t)(lv >> 5) * (uint32_t)(a.npad * sizeof(T));
+            oI = colpart + (uint32_t)g[(lv & 31) >> 2] * 64u + 16u * (lv & 3);
+            oJ = colpart + (uint32_t)g[8 + ((lv & 31) >> 2)] * 64u + 16u * (lv & 3);
+        } else {
+            oI = (uint32_t)g[lv >> 3] * 128u + 16u * (lv & 7);
+            oJ = (uint32_t)g[8 + (lv >> 3)] * 128u + 16u * (lv & 7);
+        }
+    };
+    // requests the first `valid` columns of a chunk (the tail of a layer's last chunk is not fetched) of the tile in ring
+    // slot `ms`; returns the number of direct-to-LDS instructions THIS wave issued
+    auto stage_chunk = [&](int col, int valid, int st, int ms) __attribute__((always_inline)) -> int {
         // up to LOADS / 2 instructions per side and wave, each 64 lanes x 16 B = COLS columns x (BT nodes x sizeof(T)) bytes
         constexpr int LANES_PER_COL = BT * (int)sizeof(T) / 16;
         constexpr int COLS = 64 / LANES_PER_COL;
         static_assert((CH / COLS) % NW == 0, "stage instructions must divide over the waves");
+        uint32_t offI, offJ;
+        operand_offsets(ms, offI, offJ);
         asm volatile("" ::: "memory");               // no load / store moves across the request: vm_seq below relies on the order
         const uint32_t dst_lds = lds_base + (uint32_t)(st * STAGE * sizeof(T));
-        const uint32_t lane_off = (uint32_t)(l / LANES_PER_COL) * (uint32_t)(a.npad * sizeof(T)) + 16u * (l % LANES_PER_COL);
         int issued = 0;
 #pragma unroll
         for (int k = 0; k < CH / COLS / NW; ++k) {
             const int ins = k * NW + w;
             if (ins * COLS < valid) {
-                glds16_s(reinterpret_cast<uint64_t>(XI + (int64_t)(col + ins * COLS) * a.npad + ri0), lane_off,
+                glds16_s(reinterpret_cast<uint64_t>(XI + (int64_t)(col + ins * COLS) * a.npad), offI,
                          dst_lds + (uint32_t)(ins * COLS * BT * sizeof(T)));
-                glds16_s(reinterpret_cast<uint64_t>(XJ + (int64_t)(col + ins * COLS) * a.npad + rj0), lane_off,
+                glds16_s(reinterpret_cast<uint64_t>(XJ + (int64_t)(col + ins * COLS) * a.npad), offJ,
                          dst_lds + (uint32_t)((CH * BT + ins * COLS * BT) * sizeof(T)));
                 issued += 2;
             }
@@ -721,43 +820,65 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         asm volatile("" ::: "memory");
         return issued;
     };
-    // one 1-KiB instruction per vector and side (128 doubles; a 64-node tile uses the first half), dealt over the waves;
-    // issued in front of the tile's first chunk, so the wait for that chunk covers them
-    auto stage_aux = [&](int64_t ri0, int64_t rj0, int buf) __attribute__((always_inline)) -> int {
+    // one 1-KiB instruction per vector and side (128 doubles), dealt over the waves, and the suffix sums of the rank
+    // segments (512 B: the longer side only); issued in front of the tile's first chunk, so the wait for that chunk covers them
+    auto stage_aux = [&](int buf, int ms) __attribute__((always_inline)) -> int {
         int issued = 0;
+        const int *g = meta + ms * META;
+        const int lv = lane();
+        const uint32_t aoffI = (uint32_t)g[lv >> 3] * 128u + 16u * (lv & 7), aoffJ = (uint32_t)g[8 + (lv >> 3)] * 128u + 16u * (lv & 7);
+        asm volatile("" ::: "memory");
         for (int v = 0; v < a.n_aux; ++v) {
             if ((v & (NW - 1)) != w) continue;
             gcdouble *src = v < a.n_seg ? ginv + (int64_t)v * a.npad : (gpoint ? gpoint : gH);
-            const uint32_t dst = lds_base + (uint32_t)(reinterpret_cast<char *>(aux + (buf * a.n_aux + v) * AUX_STRIDE) - reinterpret_cast<char *>(lds_raw));
-            glds16_s(reinterpret_cast<uint64_t>(src + ri0), 16u * l, dst);
-            glds16_s(reinterpret_cast<uint64_t>(src + rj0), 16u * l, dst + 1024u);
+            const uint32_t dst = lds_off(aux + (buf * a.n_aux + v) * AUX_STRIDE);
+            glds16_s(reinterpret_cast<uint64_t>(src), aoffI, dst);
+            glds16_s(reinterpret_cast<uint64_t>(src), aoffJ, dst + 1024u);
             issued += 2;
         }
-        return issued;
-    };
-    // raw ring maxima of the granules a tile touches (lane s: segment s); consumed one tile later
-    // (a tile that does not start on a granule boundary -- a row block at any multiple of 4 -- touches three granules per side)
-    auto issue_rmax = [&](int64_t ri0, int64_t rj0, uint32_t (&raw)[6]) __attribute__((always_inline)) {
-        raw[0] = raw[1] = raw[2] = raw[3] = raw[4] = raw[5] = 0;
-        if constexpr (SEG) {
-            if (w == 0 && sd.rank_col0 >= 0) {
-                const uint32_t *rm = a.rmax + (int64_t)l * a.ngran;
-                raw[0] = rm[ri0 >> 6];
-                raw[1] = rm[(ri0 + BT - 1) >> 6];
-                raw[2] = rm[rj0 >> 6];
-                raw[3] = rm[(rj0 + BT - 1) >> 6];
-                raw[4] = rm[(ri0 + BT / 2) >> 6];
-                raw[5] = rm[(rj0 + BT / 2) >> 6];
+        if constexpr (SEG && U32) {
+            for (int v = 0; v < a.n_seg; ++v) {
+                if (((v + 3) & (NW - 1)) != w) continue;          // (the waves that carry no per-node vector first)
+                const int sm = __builtin_amdgcn_readfirstlane(smeta[buf * 4 + v]);
+                if (sm < 0) continue;
+                const uint64_t rowp = reinterpret_cast<uint64_t>(a.suf + (int64_t)(sm & 0x3fffffff) * a.npad);
+                const uint32_t dst = lds_off(sufb + (buf * a.n_seg + v) * 128);
+                // a 128-node uint32 vector: 32 lanes, 4 per granule
+                const uint32_t soff = (uint32_t)g[((sm >> 30) ? 8 : 0) + ((lv & 31) >> 2)] * 64u + 16u * (lv & 3);
+                if (lv < 32) glds16_s(rowp, soff, dst);
+                issued += 1;
             }
         }
+        asm volatile("" ::: "memory");
+        return issued;
     };
-    // decide bin form / rank form per segment and write the tile's chunk list + its length into list buffer `buf`
-    // (wave 0; the other waves read them behind the next barrier)
-    auto plan = [&](const uint32_t (&raw)[6], int buf) __attribute__((always_inline)) {
+    // per-tile inputs of the plan, requested two tiles ahead by wave 0: the largest member counts of the two sides (lanes
+    // 16-23: segment (l - 16) & 3, I side then J side) and the tile's granule ids (lanes 0-15)
+    auto issue_meta = [&](int mti, int mtj) __attribute__((always_inline)) -> int {
+        int v = 0;
+        if (w == 0) {
+            const int l = lane();
+            if (l < 16) v = l < 8 ? a.gl_i[(int64_t)8 * mti + l] : a.gl_j[(int64_t)8 * mtj + (l - 8)];
+            if constexpr (SEG) {
+                if (l >= 16 && l < 24 && ((l - 16) & 3) < a.n_seg && a.tmax_i)
+                    v = (int)(l < 20 ? a.tmax_i[(int64_t)(l - 16) * a.ntl_i + mti] : a.tmax_j[(int64_t)(l - 20) * a.ntl_j + mtj]);
+            }
+        }
+        return v;
+    };
+    // ... and parked in the ring (wave 0) while nothing younger than operand requests is outstanding
+    auto park_meta = [&](int v, int ms) __attribute__((always_inline)) {
+        if (w == 0) { const int l = lane(); if (l < META) meta[ms * META + l] = v; }
+    };
+    // decide bin form / rank form per segment from the tile's ring slot and write its chunk list + length and its suffix
+    // rows into buffer `buf` (wave 0; the other waves read them behind the next barrier)
+    auto plan = [&](int ms, int buf) __attribute__((always_inline)) {
         if constexpr (SEG) {
             if (w != 0) return;
-            const uint32_t R = max(max(max(raw[0], raw[1]), max(raw[2], raw[3])), max(raw[4], raw[5]));
-            const int pre = plan_segment<CH, KIND == K_SAD16>(sd, l < a.n_seg, R, l, clist + buf * a.list_cap);
+            const int l = lane();
+            const uint32_t RI = l < 4 ? (uint32_t)meta[ms * META + 16 + l] : 0u, RJ = l < 4 ? (uint32_t)meta[ms * META + 20 + l] : 0u;
+            SegDesc sd = segd[l & 3];
+            const int pre = plan_segment_min<CH, KIND == K_SAD16>(sd, l < a.n_seg, RI, RJ, l, clist + buf * a.list_cap, smeta + buf * 4);
             if (l == 63) nlist[buf] = pre;
         }
     };
@@ -777,32 +898,32 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     // ---- prologue: plan of the first tile, coordinates of the next two ----
     int ti, tj;
     tile_from_index(a, t, ti, tj);
-    int64_t i0 = uniform64(a.i_begin + (int64_t)ti * BT), j0 = uniform64(a.j_begin + (int64_t)tj * BT);
-    uint32_t raw[6];
-    issue_rmax(i0, j0, raw);
     int cur = 0;                                      // list buffer of the tile being computed
-    plan(raw, cur);
-    if constexpr (SEG) { if constexpr (NW > 1) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    int n0 = planned_chunks(cur);
+    int ms = 0;                                       // its slot of the meta ring (next tile: ms + 1, the one after: ms + 2, mod 3)
+    auto ring = [](int k) __attribute__((always_inline)) { return k >= 3 ? k - 3 : k; };
     const int t1 = t + nwx, t2 = t + 2 * nwx;
     bool has1 = t1 < hi, has2 = t2 < hi;
     int ti1 = 0, tj1 = 0, ti2 = 0, tj2 = 0;
     if (has1) tile_from_index(a, t1, ti1, tj1);
     if (has2) tile_from_index(a, t2, ti2, tj2);
-    int64_t i1 = uniform64(a.i_begin + (int64_t)ti1 * BT), j1 = uniform64(a.j_begin + (int64_t)tj1 * BT);
-    uint32_t raw1[6];
-    if (has1) issue_rmax(i1, j1, raw1);
+    park_meta(issue_meta(ti, tj), 0);
+    if (has1) park_meta(issue_meta(ti1, tj1), 1);
+    plan(0, cur);
+    __syncthreads();
+    int n0 = planned_chunks(cur);
 
     int vm_seq = 0;                                   // vector-memory operations issued so far (lower bound: masked stores are not counted)
     int seq_of_stage[2] = {0, 0};                     // vm_seq right after the loads of the chunk that sits in each LDS stage
     int st = 0;                                       // LDS stage of the next chunk to be computed
     int ahead = 0;                                    // chunks of the current tile whose loads are already issued
-    vm_seq += stage_aux(i0, j0, cur);
-    if (n0 > 0) { vm_seq += stage_chunk(chunk_col(cur, 0), chunk_valid(cur, 0), i0, j0, 0); seq_of_stage[0] = vm_seq; ahead = 1; }
-    if (n0 > 1) { vm_seq += stage_chunk(chunk_col(cur, 1), chunk_valid(cur, 1), i0, j0, 1); seq_of_stage[1] = vm_seq; ahead = 2; }
+    vm_seq += stage_aux(cur, ms);
+    if (n0 > 0) { vm_seq += stage_chunk(chunk_col(cur, 0), chunk_valid(cur, 0), 0, ms); seq_of_stage[0] = vm_seq; ahead = 1; }
+    if (n0 > 1) { vm_seq += stage_chunk(chunk_col(cur, 1), chunk_valid(cur, 1), 1, ms); seq_of_stage[1] = vm_seq; ahead = 2; }
     unsigned long long work = 0;
     bool first_landed = false;
+#if HSD_STAMPS
     unsigned long long cyc_store = 0, cyc_loop = 0, cyc_epi = 0, n_tiles = 0;      // HSD_DEBUG bit 3 only
+#endif
 
     while (true) {
         double acc[TR][TC];
@@ -817,26 +938,28 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #pragma unroll
                 for (int c = 0; c < TC; ++c) part[r][c] = (T)0;
         }
-        // the next tile's plan: its ring maxima were requested one tile ago
+        // the next tile's plan: its inputs were parked in the ring during the previous tile
         int n1 = 0;
-        if (has1) plan(raw1, cur ^ 1);
-        wg_barrier();                                 // list of the next tile visible; every wave is done with the previous tile's LDS
+        if (has1) plan(ring(ms + 1), cur ^ 1);
+        wg_barrier();                                 // plan of the next tile visible; every wave is done with the previous tile's LDS
         if (has1) n1 = planned_chunks(cur ^ 1);
-        // ... the maxima of the tile after it are requested now
-        const int64_t i2 = uniform64(a.i_begin + (int64_t)ti2 * BT), j2 = uniform64(a.j_begin + (int64_t)tj2 * BT);
-        if (has2) issue_rmax(i2, j2, raw1);            // (not counted in vm_seq: only operations that are certainly issued are)
+        // ... the inputs of the tile after it are requested now (picked up behind the chunk loop)
+        const int meta2 = has2 ? issue_meta(ti2, tj2) : 0;     // (not counted in vm_seq: only operations that are certainly issued are)
         // ... and the tile after that is drawn from the XCD's counter (the answer is picked up at the end of this tile)
         int drawn = 0;
         if (w == 0 && l == 0 && src >= 0) drawn = atomicAdd(a.tile_ctr + src, 1);
         int ahead1 = 0;                               // chunks of the NEXT tile already requested
-        bool aux1 = false;                            // ... and its auxiliary vectors
+        bool aux1 = false;                            // ... and its auxiliary vectors (the per-lane offsets are the next tile's from then on)
+        const bool diag = a.sym && ti == tj;          // a tile on the diagonal of a symmetric region is computed in full and not mirrored
 
         if (n0 == 0) {
             // a tile without operand chunks (no histogram layer compared): nothing below waits for its per-node vectors
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wg_barrier();
         }
+#if HSD_STAMPS
         const unsigned long long c_l0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
         for (int k = 0; k < n0; ++k) {
             int cvalid, seg = 0;
             bool ends_seg = false;
@@ -853,8 +976,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             // chunk k has landed once everything older than the operations issued after its loads has retired
             // (the first chunk of a tile was waited for before the previous tile's stores went out)
             if (!(k == 0 && first_landed)) wait_vm_young(__builtin_amdgcn_readfirstlane(vm_seq - (st ? seq_of_stage[1] : seq_of_stage[0])));
-            if constexpr (NW > 1) wg_barrier();           // every wave's part of chunk k has landed, and chunk k - 1 is consumed
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();                             // every wave's part of chunk k has landed, and chunk k - 1 is consumed
             const T *sI = sbase + st * STAGE;
             const T *sJ = sI + CH * BT;
             // the other stage is free (its chunk was consumed in the previous iteration): request the chunk after next
@@ -862,13 +984,13 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             if (k >= 1 || ahead < 2) {
                 // (k == 0 with two chunks in flight: nothing to request, both stages are taken)
                 if (ahead < n0) {
-                    vm_seq += stage_chunk(chunk_col(cur, ahead), chunk_valid(cur, ahead), i0, j0, st ^ 1);
+                    vm_seq += stage_chunk(chunk_col(cur, ahead), chunk_valid(cur, ahead), st ^ 1, ms);
                     seq_of_stage[st ^ 1] = vm_seq; ++ahead;
                 } else if (has1 && !aux1) {
-                    vm_seq += stage_aux(i1, j1, cur ^ 1);     // the next tile's vectors, then its first chunk
+                    vm_seq += stage_aux(cur ^ 1, ring(ms + 1));     // the next tile's vectors, then its first chunk
                     aux1 = true;
                     if (n1 > 0) {
-                        vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), i1, j1, st ^ 1);
+                        vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), st ^ 1, ring(ms + 1));
                         seq_of_stage[st ^ 1] = vm_seq; ahead1 = 1;
                     }
                 }
@@ -932,26 +1054,46 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             if constexpr (SEG) {
                 if (ends_seg) {
-                    double vi_[TR], vj_[TC];
+                    // the layer closes: sum_c |..| / max(n_i, n_j) == sum * min(1/n_i, 1/n_j) (empty rings carry inv = 2).  Row by
+                    // row, with only the column side's vector held: this is where the kernel's register demand peaks (both
+                    // accumulator sets are live), and a spill here is a scratch reload that waits behind every outstanding
+                    // operand request.
                     const double *ax = aux + (cur * a.n_aux + seg) * AUX_STRIDE;      // 1/ring size, staged with the tile
+                    const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
+                    double vj_[TC];
 #pragma unroll
                     for (int cc = 0; cc < TC; ++cc) vj_[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) vi_[r] = ax[wi + 16 * (r >> 1) + (r & 1)];
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) {
-                        const double vi = vi_[r];
+                    // min form: the rank values of the longer side beyond the words both sides were read for
+                    int sm = -1;
+                    if constexpr (U32) sm = __builtin_amdgcn_readfirstlane(smeta[cur * 4 + seg]);
+                    const uint32_t *sb = sufb + (cur * a.n_seg + seg) * 128;
+                    if (U32 && sm >= 0 && (sm >> 30)) {
 #pragma unroll
                         for (int cc = 0; cc < TC; ++cc) {
-                            acc[r][cc] = fma((double)part[r][cc], fmin(vi, vj_[cc]), acc[r][cc]);
+                            const T sv = (T)sb[wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+                            for (int r = 0; r < TR; ++r) part[r][cc] += sv;
+                        }
+                    }
+                    const bool row_suffix = U32 && sm >= 0 && !(sm >> 30);
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) {
+                        const double vi = ax[wi + 16 * (r >> 1) + (r & 1)];
+                        const T sv = row_suffix ? (T)sb[wi + 16 * (r >> 1) + (r & 1)] : (T)0;
+#pragma unroll
+                        for (int cc = 0; cc < TC; ++cc) {
+                            acc[r][cc] = fma((double)(part[r][cc] + sv), fmin(vi, vj_[cc]), acc[r][cc]);
                             part[r][cc] = (T)0;
                         }
+                        HSD_PIN_ORDER;
                     }
                 }
             }
             st ^= 1;
         }
+#if HSD_STAMPS
         const unsigned long long c_l1 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
         // the second chunk of the next tile goes out BEFORE this tile's stores: its loads then do not queue behind them
         if (w == 0 && l == 0) {
             // position of the drawn tile in the order, or -1 when every run is exhausted.  A workgroup whose own XCD's run
@@ -969,14 +1111,18 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             nlist[2] = pos;
         }
+        // the inputs of the tile after next have arrived (they were requested a tile's worth of arithmetic ago): into the ring,
+        // BEFORE this tile's stores -- hipcc does not see the hand-issued stores below, and a wait for these loads behind
+        // them would be a wait for the stores
+        if (has2) park_meta(meta2, ring(ms + 2));
         wg_barrier();                                 // the stage of the last chunk is free only when every wave has consumed it
-        if (has1 && !aux1) { vm_seq += stage_aux(i1, j1, cur ^ 1); aux1 = true; }
+        if (has1 && !aux1) { vm_seq += stage_aux(cur ^ 1, ring(ms + 1)); aux1 = true; }
         if (ahead1 == 0 && n1 > 0) {
-            vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), i1, j1, st);
+            vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), st, ring(ms + 1));
             seq_of_stage[st] = vm_seq; ahead1 = 1;
         }
         if (ahead1 == 1 && n1 > 1) {
-            vm_seq += stage_chunk(chunk_col(cur ^ 1, 1), chunk_valid(cur ^ 1, 1), i1, j1, st ^ 1);
+            vm_seq += stage_chunk(chunk_col(cur ^ 1, 1), chunk_valid(cur ^ 1, 1), st ^ 1, ring(ms + 1));
             seq_of_stage[st ^ 1] = vm_seq; ahead1 = 2;
         }
         // A wave can have 63 vector-memory operations outstanding at most, and they retire in order: a wait for operand
@@ -990,6 +1136,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         // ---- epilogue arithmetic ----
         if constexpr (KIND == K_DOT) {
             double hj[TC];
+            const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
             const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
             for (int cc = 0; cc < TC; ++cc) hj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
@@ -1005,6 +1152,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         }
         if (gpoint) {
             double pj[TC];
+            const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
             const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
             for (int cc = 0; cc < TC; ++cc) pj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
@@ -1017,24 +1165,35 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         }
         // ---- stores ----
         asm volatile("" ::: "memory");
+#if HSD_STAMPS
         const unsigned long long c_s0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+        const bool mirror = a.mirror && !diag;
+        // this tile's granules: row / column bases of its results
+        int GI[4], GJ[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            GI[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 4 * (w >> 1) + qq]);
+            GJ[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 8 + 4 * (w & 1) + qq]);
+        }
         if constexpr (TOPK) {
           if (!((a.dbg & 1) && acc[0][0] != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
-            // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (interior tiles
-            // only: i != j, no masks).  tau is read per tile: the host tightens it between the phases of a sweep.
+            // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (a tile on the
+            // diagonal holds both orientations of its pairs: row i only, and not i itself).  tau is read per tile: the host
+            // tightens it between the phases of a sweep.
             gcdouble *tau = (gcdouble *)a.tau;
             double tj_[TC];
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) tj_[cc] = a.mirror ? tau[j0 + wj + 16 * (cc >> 1) + (cc & 1)] : -1.0;
+            for (int cc = 0; cc < TC; ++cc) tj_[cc] = mirror ? tau[(int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1)] : -1.0;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const int64_t i = i0 + wi + 16 * (r >> 1) + (r & 1);
+                const int64_t i = (int64_t)16 * GI[r >> 1] + 2 * ly + (r & 1);
                 const double ti_ = tau[i];
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
-                    const int64_t j = j0 + wj + 16 * (cc >> 1) + (cc & 1);
+                    const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
                     const double v = acc[r][cc];
-                    if (v <= ti_) {
+                    if (v <= ti_ && i != j) {
                         const int slot = atomicAdd(a.cand_cnt + i, 1);
                         if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
                     }
@@ -1049,51 +1208,72 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         } else if ((a.dbg & 1) && acc[0][0] != -1.0) {
             // ablation: no stores
         } else {
-            // HSD_DEBUG bit 4 (measurement): every tile stores into the first tile's place -- the same store instructions
+            // HSD_DEBUG bit 4 (measurement): every tile stores into the first granules' place -- the same store instructions
             // without the HBM write stream (the lines stay in L2)
-            const int64_t si0 = (a.dbg & 16) ? a.i_begin : i0, sj0 = (a.dbg & 16) ? a.j_begin + BT : j0;
-            gdouble *pd = out + (si0 + wi - a.rbase) * a.ld + (sj0 + wj);
+            if (a.dbg & 16) {
 #pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                gdouble *row = pd + (int64_t)(16 * (r >> 1) + (r & 1)) * a.ld;
-#pragma unroll
-                for (int qq = 0; qq < TC / 2; ++qq) store2_full<true>(row + 16 * qq, acc[r][2 * qq], acc[r][2 * qq + 1], nt);
+                for (int qq = 0; qq < 4; ++qq) { GI[qq] = 4 * (w >> 1) + qq; GJ[qq] = 8 + 4 * (w & 1) + qq; }
             }
-            vm_seq += TR * TC / 2;
-            if (a.mirror) {
-                gdouble *pm = out + (sj0 + wj - a.rbase) * a.ld + (si0 + wi);
+            // Row 16 GI[q] + 2 ly + par, columns 16 GJ[q'] + 2 lx + {0, 1}: a scalar base per (q, q') and one 32-bit lane
+            // offset per parity -- the instruction form with a scalar address, spelled out (with vector addresses hipcc keeps
+            // 64-bit lane offsets in registers across the tile loop and spills them).  Formed per tile from the lane id (the
+            // empty asm keeps them from being hoisted out of the tile loop into four more long-lived registers).
+            const int lv = lane(), lyv = lv >> 3, lxv = lv & 7;
+            const uint32_t ld8 = (uint32_t)a.ld * 8u;
+            const uint32_t vd0 = (uint32_t)(2 * lyv) * ld8 + (uint32_t)(16 * lxv), vd1 = vd0 + ld8;
+            auto put = [&](auto NT_) __attribute__((always_inline)) {
+                constexpr bool NTS = decltype(NT_)::value;
 #pragma unroll
-                for (int cc = 0; cc < TC; ++cc) {
-                    gdouble *row = pm + (int64_t)(16 * (cc >> 1) + (cc & 1)) * a.ld;
+                for (int r = 0; r < TR; ++r) {
+                    const int64_t rowb = ((int64_t)16 * GI[r >> 1] - a.rbase) * a.ld;
 #pragma unroll
-                    for (int qq = 0; qq < TR / 2; ++qq) store2_full<true>(row + 16 * qq, acc[2 * qq][cc], acc[2 * qq + 1][cc], nt);
+                    for (int qq = 0; qq < TC / 2; ++qq)
+                        gstore16_s<NTS>(reinterpret_cast<uint64_t>(a.out + rowb + (int64_t)16 * GJ[qq]), (r & 1) ? vd1 : vd0, v2f64{acc[r][2 * qq], acc[r][2 * qq + 1]});
                 }
-                vm_seq += TR * TC / 2;
-            }
+                if (mirror) {
+                    const uint32_t vm0 = (uint32_t)(2 * lxv) * ld8 + (uint32_t)(16 * lyv), vm1 = vm0 + ld8;
+#pragma unroll
+                    for (int cc = 0; cc < TC; ++cc) {
+                        const int64_t rowb = ((int64_t)16 * GJ[cc >> 1] - a.rbase) * a.ld;
+#pragma unroll
+                        for (int qq = 0; qq < TR / 2; ++qq)
+                            gstore16_s<NTS>(reinterpret_cast<uint64_t>(a.out + rowb + (int64_t)16 * GI[qq]), (cc & 1) ? vm1 : vm0, v2f64{acc[2 * qq][cc], acc[2 * qq + 1][cc]});
+                    }
+                }
+            };
+#if HSD_STAMPS
+            if (nt) put(std::true_type{}); else put(std::false_type{});       // HSD_DEBUG bit 2: plain instead of non-temporal stores
+#else
+            put(std::true_type{});
+#endif
+            vm_seq += mirror ? TR * TC : TR * TC / 2;
         }
-        // (edge and diagonal tiles are not in this kernel's list: the one-tile kernel stores them with per-element masks)
+#if HSD_STAMPS
         if (a.dbg & 8) {
             asm volatile("" ::: "memory");
             const unsigned long long c_s1 = __builtin_amdgcn_s_memtime();
             cyc_loop += c_l1 - c_l0; cyc_epi += c_s0 - c_l1; cyc_store += c_s1 - c_s0; ++n_tiles;
         }
+#endif
         if (!has1) break;
         // ---- rotate: next tile becomes current ----
-        i0 = i1; j0 = j1; i1 = i2; j1 = j2;
-        n0 = n1; cur ^= 1; ahead = ahead1;
+        ti = ti1; tj = tj1; ti1 = ti2; tj1 = tj2;
+        n0 = n1; cur ^= 1; ms = ring(ms + 1); ahead = ahead1;
         has1 = has2;
         const int t3 = __builtin_amdgcn_readfirstlane(nlist[2]);
         has2 = t3 >= 0;
         if (has2) tile_from_index(a, t3, ti2, tj2);
     }
     if (a.work && threadIdx.x == 0) atomicAdd(a.work, work * (unsigned long long)(BT * BT));
-    if ((a.dbg & 8) && a.cand_val && threadIdx.x == 0) {
-        // measurement hook: (start, end) of this workgroup in 100 MHz ticks, in a buffer nothing else reads
-        unsigned long long *st = reinterpret_cast<unsigned long long *>(a.cand_val) + 6 * (size_t)blockIdx.x;
-        st[0] = stamp0;
-        st[1] = __builtin_amdgcn_s_memrealtime();
-        st[2] = cyc_loop; st[3] = cyc_epi; st[4] = cyc_store; st[5] = n_tiles;
+#if HSD_STAMPS
+    if ((a.dbg & 8) && a.stamps && threadIdx.x == 0) {
+        // measurement hook: (start, end) of this workgroup in 100 MHz ticks
+        unsigned long long *sp = a.stamps + 6 * (size_t)blockIdx.x;
+        sp[0] = stamp0;
+        sp[1] = __builtin_amdgcn_s_memrealtime();
+        sp[2] = cyc_loop; sp[3] = cyc_epi; sp[4] = cyc_store; sp[5] = n_tiles;
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1171,7 +1351,8 @@ __global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict
 // that would need more take the bin columns).
 template <bool PACK>
 __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_col0, const int *__restrict__ seg_rank_cap,
-                                 const int *__restrict__ seg_first_bin, uint32_t *__restrict__ X) {
+                                 const int *__restrict__ seg_first_bin, const int *__restrict__ seg_suf_row0, uint32_t *__restrict__ X,
+                                 uint32_t *__restrict__ SUF) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
     const int sgi = blockIdx.y;
@@ -1181,21 +1362,33 @@ __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_co
     const int cap = seg_rank_cap[sgi], fb = seg_first_bin[sgi];
     const uint32_t theta = fb > 0 ? (uint32_t)p.support[fb - 1] : 0u;
     uint32_t *col = X + (int64_t)seg_rank_col0[sgi] * p.npad + i;
+    // suffix sums (min form of the persistent kernel): suf[w] = sum of ALL the node's rank values from word w on, i.e. the
+    // whole sum above theta minus what the first w words hold -- also where the rank columns themselves are cut off at the cap
+    uint32_t *suf = SUF + (int64_t)seg_suf_row0[sgi] * p.npad + i;
+    uint32_t total = 0;
+    for (int b = p.B - 1; b >= fb; --b) total += c[b] * ((uint32_t)p.support[b] - theta);
     const int want = PACK ? 2 * cap : cap;           // values to emit
     int r = 0;
-    uint32_t lo = 0;
+    uint32_t lo = 0, prefix = 0;
+    suf[0] = total;
     for (int b = p.B - 1; b >= fb && r < want; --b) {
         const uint32_t v = (uint32_t)p.support[b] - theta;
         for (uint32_t m = c[b]; m > 0 && r < want; --m, ++r) {
+            prefix += v;
             if (PACK) {
-                if (r & 1) col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16);
+                if (r & 1) { col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16); suf[(int64_t)((r >> 1) + 1) * p.npad] = total - prefix; }
                 else lo = v;
             } else {
                 col[(int64_t)r * p.npad] = v;
+                suf[(int64_t)(r + 1) * p.npad] = total - prefix;
             }
         }
     }
-    if (PACK && (r & 1)) col[(int64_t)(r >> 1) * p.npad] = lo;      // odd count: upper half stays 0
+    if (PACK && (r & 1)) {                            // odd count: upper half stays 0
+        col[(int64_t)(r >> 1) * p.npad] = lo;
+        suf[(int64_t)((r >> 1) + 1) * p.npad] = total - prefix;
+    }
+    // (rows beyond the node's own words stay 0: the matrix was cleared)
 }
 
 // above[(s * n_cand + q) * npad + i] = members of ring layer s of node i with bin index >= cand_bin[q]
@@ -1220,6 +1413,17 @@ __global__ void granule_max_kernel(const uint32_t *__restrict__ ntot, int64_t np
     uint32_t v = ntot[(int64_t)sgi * npad + (int64_t)g * 64 + threadIdx.x];
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_down((int)v, o, 64));
     if (threadIdx.x == 0) rmax[(int64_t)sgi * ngran + g] = v;
+}
+
+// g16[k][g] = largest of vec[k][16 g .. 16 g + 15] (k: layer x candidate threshold)
+__global__ void granule16_max_kernel(const uint32_t *__restrict__ vec, int64_t npad, int ngran16, uint32_t *__restrict__ g16) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (g >= ngran16) return;
+    const uint32_t *v = vec + (int64_t)k * npad + (int64_t)g * 16;
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m = max(m, v[e]);
+    g16[(int64_t)k * ngran16 + g] = m;
 }
 
 // KL: P = (c + alpha) / (n + alpha B), LP = log P, H = sum P LP.  symmetric: X = [P ; LP], Y = [LP ; P].
@@ -1336,11 +1540,18 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
     const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
     if (n_phases < 1) n_phases = 1;
     const int key = std::max(S, 1) + (phase << 8) + (n_phases << 12) + (deal << 16) + (cls << 20) + ((int)part_i << 24) + ((int)part_j << 25);
-    for (const auto &c : ctx->tile_lists)
+    for (size_t k = 0; k < ctx->tile_lists.size(); ++k) {
+        const auto &c = ctx->tile_lists[k];
         if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == key) {
-            if (count) *count = c.count;
-            return reinterpret_cast<const int2 *>(c.d);
+            // least recently used first: a hit moves to the back, so the lists of the call in progress (a phased sweep
+            // takes a few dozen) are the last to be evicted
+            const hsd_ctx::TileList hit = c;
+            ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)k);
+            ctx->tile_lists.push_back(hit);
+            if (count) *count = hit.count;
+            return reinterpret_cast<const int2 *>(hit.d);
         }
+    }
     const int G = std::max(S, 1);
     std::vector<int2> order;
     order.reserve(sym ? (size_t)tiles_i * (tiles_i + 1) / 2 : (size_t)tiles_i * tiles_j);
@@ -1372,7 +1583,11 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
         if (count) *count = -1;
         return nullptr;
     }
-    if (ctx->tile_lists.size() >= 64) { (void)hipFree(ctx->tile_lists.front().d); ctx->tile_lists.erase(ctx->tile_lists.begin()); }
+    if (ctx->tile_lists.size() >= 256) {
+        // (hipFree synchronises the device: rare -- 256 lists are more than any one call hands out)
+        (void)hipFree(ctx->tile_lists.front().d);
+        ctx->tile_lists.erase(ctx->tile_lists.begin());
+    }
     ctx->tile_lists.push_back({tiles_i, tiles_j, sym, key, d, (int)order.size()});
     return reinterpret_cast<const int2 *>(d);
 }
@@ -1380,10 +1595,11 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
 template <int KIND, int NW, bool TOPK = false>
 hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     auto kern = pair_stream_kernel<KIND, NW, TOPK>;
-    constexpr int CH = stream_chunk_cols(KIND, NW);
-    constexpr int BT = NW == 4 ? 128 : 64;
-    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 +
-                       (size_t)2 * a.n_aux * 256 * sizeof(double);
+    constexpr int CH = stream_chunk_cols(KIND);
+    constexpr int BT = 128;
+    // stages, chunk lists + lengths, granule ids + suffix rows of two tiles, per-node vectors, suffix sums
+    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 24 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
+                       (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t);
     // the attribute is per device: remembered per context (one context per GPU), not per process
     size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
     if (lds > attr_lds) {
@@ -1402,12 +1618,12 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     if (a.dbg & 8) {
-        // HSD_DEBUG bit 3: per-workgroup lifetimes -> stderr (synchronises; measurement only)
+        // HSD_DEBUG bit 3: per-workgroup lifetimes -> stderr (synchronises; measurement only; its own buffer)
         PairArgs b = a;
         unsigned long long *d_st = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&d_st), (size_t)grid * 48) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemset(d_st, 0, (size_t)grid * 48);
-        b.cand_val = reinterpret_cast<double *>(d_st);
+        b.stamps = d_st;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, b);
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h6((size_t)grid * 6), h((size_t)grid * 2);
@@ -1419,6 +1635,7 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
         std::vector<double> life, endt;
         for (int g = 0; g < grid; ++g) if (h[2 * g]) { life.push_back((h[2 * g + 1] - h[2 * g]) * 1e-2); endt.push_back((h[2 * g + 1] - t0) * 1e-2); }
         std::sort(endt.begin(), endt.end());
+        if (endt.empty()) return hipGetLastError();
         double per_xcd[8] = {0};
         int cnt[8] = {0};
         for (int g = 0; g < grid; ++g) if (h[2 * g]) { per_xcd[g & 7] += (h[2 * g + 1] - t0) * 1e-2; ++cnt[g & 7]; }
@@ -1435,21 +1652,22 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// The persistent kernel takes every region whose operand slices and output rows are 16-byte aligned (direct-to-LDS
-// loads, vector stores), except the fp64 zero-pad fallback (its two fp64 accumulator sets do not fit 8 x 8 pairs per
-// lane); the fused k-nearest consumer runs its own instantiation (TOPK).  HSD_STREAM=0 or an explicit HSD_TILE: the one-tile-per-workgroup kernel for
-// every tile (A/B measurements; the tests run both and compare them bit for bit).
+// The persistent kernel takes every region whose rows and columns start on a 16-node granule and whose output pairs are
+// 16-byte aligned, except the fp64 zero-pad fallback (its two fp64 accumulator sets do not fit 8 x 8 pairs per lane); the
+// fused k-nearest consumer runs its own instantiation (TOPK).  HSD_STREAM=0 or an explicit HSD_TILE: the
+// one-tile-per-workgroup kernel for every tile (A/B measurements; the tests run both and compare them bit for bit).
 int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
     if (const char *ew = getenv("HSD_STREAM")) if (atoi(ew) == 0) return 0;
     if (getenv("HSD_TILE")) return 0;
     if (ctx->mode == PAIR_ZP_F64) return 0;
-    const bool aligned = (a.i_begin % 4 == 0) && (a.j_begin % 4 == 0) && (a.npad % 4 == 0) &&
-                         (a.tau || ((a.ld % 2 == 0) && (reinterpret_cast<uintptr_t>(a.out) % 16 == 0)));
+    const bool aligned = (a.i_begin % 16 == 0) && (a.j_begin % 16 == 0) && (a.npad % 4 == 0) &&
+                         (a.tau || ((a.ld % 2 == 0) && a.ld < (int64_t)30000000 && (reinterpret_cast<uintptr_t>(a.out) % 16 == 0)));
     if (!aligned) return 0;
     // a resident workgroup needs a few dozen tiles to amortise its start-up and to level the tail (measured at ER N = 10k,
     // 3160 tiles for 512 workgroups: zero-pad 0.210 ms against 0.178 ms with one 64 x 64 tile per workgroup); HSD_STREAM=1 forces it
-    const int64_t ti = (a.i_end - a.i_begin + 127) / 128, tj = (a.j_end - a.j_begin + 127) / 128;
+    const int64_t ti = (a.i_end - a.i_begin) / 128, tj = (a.j_end - a.j_begin) / 128;
     const int64_t tiles = a.sym ? ti * (ti + 1) / 2 : ti * tj;
+    if (tiles <= 0) return 0;
     const char *ew = getenv("HSD_STREAM");
     if (!(ew && atoi(ew) != 0) && tiles < 16 * 2 * (int64_t)ctx->prop.multiProcessorCount) return 0;
     return 4;
@@ -1468,11 +1686,151 @@ hipError_t launch_one_tile(hsd_ctx *ctx, const PairArgs &a, int BT, hipStream_t 
     }
 }
 
-int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
+// tmax[s * ntiles + t] = most members above layer s's threshold among the nodes of list tile t (its eight granules)
+__global__ void list_tile_max_kernel(const int32_t *__restrict__ gl, int ntiles, const uint32_t *__restrict__ rmax16, int ngran16, int n_seg,
+                                     uint32_t *__restrict__ tmax) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (int64_t)ntiles * n_seg) return;
+    const int s = (int)(k / ntiles), t = (int)(k % ntiles);
+    uint32_t m = 0;
+    for (int e = 0; e < 8; ++e) m = max(m, rmax16[(int64_t)s * ngran16 + gl[(int64_t)8 * t + e]]);
+    tmax[k] = m;
+}
+
+// The granule list of the node range [begin, end) (begin on a granule, a whole number of 128-node tiles): its granules in
+// the order hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank
+// segments.  Cached per context until the operands are released; false if it cannot be built.
+bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd_ctx::GranList *out) {
+    const char *es = getenv("HSD_GRAN_SORT");
+    const bool sorted = !ctx->gran_order.empty() && !(es && atoi(es) == 0);
+    const int64_t key_end = sorted ? end : -end;                 // (the two orders of a range are cached side by side)
+    for (const auto &g : ctx->gran_lists)
+        if (g.begin == begin && g.end == key_end) { *out = g; return true; }
+    const int64_t g0 = begin / 16, g1 = end / 16;
+    std::vector<int32_t> gl;
+    gl.reserve((size_t)(g1 - g0));
+    if (sorted) { for (int32_t g : ctx->gran_order) if (g >= g0 && g < g1) gl.push_back(g); }
+    else for (int64_t g = g0; g < g1; ++g) gl.push_back((int32_t)g);
+    if ((int64_t)gl.size() != g1 - g0 || gl.size() % 8 != 0 || gl.empty()) return false;
+    hsd_ctx::GranList L{begin, key_end, nullptr, nullptr, (int)(gl.size() / 8)};
+    if (hipMalloc(reinterpret_cast<void **>(&L.d_gl), gl.size() * sizeof(int32_t)) != hipSuccess) return false;
+    if (hipMemcpy(L.d_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(L.d_gl); return false; }
+    if (ctx->d_rmax16 && ctx->n_seg > 0) {
+        const int64_t cnt = (int64_t)L.ntiles * ctx->n_seg;
+        if (hipMalloc(reinterpret_cast<void **>(&L.d_tmax), (size_t)cnt * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(L.d_gl); return false; }
+        // on the stream of the launch that asked for the list: ordered in front of it (a later call finds the list finished --
+        // every hsd_pair_* call joins its streams before it returns)
+        hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, L.d_gl, L.ntiles, ctx->d_rmax16,
+                           ctx->ngran16, ctx->n_seg, L.d_tmax);
+    }
+    ctx->gran_lists.push_back(L);
+    *out = L;
+    return true;
+}
+
+int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool allow_stream = true) {
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    const int nw = stream_waves(ctx, a);
-    if (nw) BT = nw == 4 ? 128 : 64;
-    else if (BT == 128 && !getenv("HSD_TILE") && ctx->mode != PAIR_ZP_F64) {
+    if (a.i_end <= a.i_begin || a.j_end <= a.j_begin) return HSD_OK;
+    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
+    const int n_aux = ctx->n_seg + ((wass ? a.point != nullptr : true) ? 1 : 0);
+    // LDS budget of the persistent kernel (2 workgroups per CU): two tiles x three vectors x 2 KiB; deeper hierarchies
+    // (more than two compared histogram layers + ring 0) take the one-tile kernel for every tile
+    const int nw = (allow_stream && n_aux <= 3) ? stream_waves(ctx, a) : 0;
+    if (nw) {
+        // Whole 128-node tiles of both ranges: the persistent kernel, tiles composed from the ranges' granule lists (a tile on
+        // the diagonal of a symmetric region is computed in full and not mirrored: no masks anywhere).  What is left over at
+        // the end of a range (< 128 nodes) are strips for the one-tile kernel with its masked stores, in natural order.
+        const int64_t i_full = a.i_begin + (a.i_end - a.i_begin) / 128 * 128, j_full = a.j_begin + (a.j_end - a.j_begin) / 128 * 128;
+        hsd_ctx::GranList LI{}, LJ{};
+        bool ok = gran_list(ctx, a.i_begin, i_full, stream, &LI);
+        if (ok) { if (a.sym) LJ = LI; else ok = gran_list(ctx, a.j_begin, j_full, stream, &LJ); }
+        if (ok) {
+            PairArgs b = a;
+            b.i_end = i_full; b.j_end = j_full;
+            b.tiles_i = LI.ntiles; b.tiles_j = LJ.ntiles;
+            const int64_t nb = a.sym ? (int64_t)b.tiles_i * (b.tiles_i + 1) / 2 : (int64_t)b.tiles_i * b.tiles_j;
+            if (nb > 0x7fffffff) return hsd_fail(ctx, HSD_ERR_TOO_LARGE, "too many tiles (%lld)", (long long)nb);
+            // The Wasserstein kinds compute a tile on the diagonal of a symmetric region in full inside the persistent kernel
+            // (|a - b| sums are the same bits in both orientations and an exact 0 on the diagonal).  KL is mirrored from the
+            // upper triangle (model/HSD.py:132-134) and its dot products are not: its diagonal tiles keep the one-tile
+            // kernel's masks (natural composition: the KL kinds have no sorted order).
+            const bool diag_masked = a.sym && !wass;
+            int n_in = -1, n_mask = 0;
+            const int2 *l_in = tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, diag_masked ? 1 : 0, false, false, &n_in, a.phase, a.n_phases);
+            const int2 *l_mask = diag_masked ? tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, 2, false, false, &n_mask, a.phase, a.n_phases) : nullptr;
+            if (!l_in && n_in < 0 && a.n_phases <= 1 && !diag_masked) {
+                // (formula order: HSD_SUPERTILE=1 or the list could not be allocated)
+                n_in = (int)nb;
+            }
+            if (n_in >= 0 && n_mask >= 0) {
+                hipError_t e = hipSuccess;
+                b.tiles = l_in;
+                b.ntiles = n_in;
+                b.tile_ctr = ctx->d_tile_ctr + 8 * (a.ctr_slot & 3);
+                b.n_aux = n_aux;
+                b.gl_i = LI.d_gl; b.gl_j = LJ.d_gl;
+                b.tmax_i = LI.d_tmax; b.tmax_j = LJ.d_tmax;
+                b.ntl_i = LI.ntiles; b.ntl_j = LJ.ntiles;
+                b.suf = ctx->d_suf;
+                b.stamps = nullptr;
+                if (a.tau) b.dbg &= ~8;                   // (the lifetime stamps are a matrix-launch hook)
+                if (n_in > 0) {
+                    if (a.tau)
+                        switch (ctx->mode) {
+                            case PAIR_L1_F64: e = launch_stream<K_L1, 4, true>(ctx, b, stream); break;
+                            case PAIR_SAD_U32: e = launch_stream<K_SAD, 4, true>(ctx, b, stream); break;
+                            case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4, true>(ctx, b, stream); break;
+                            default: e = launch_stream<K_DOT, 4, true>(ctx, b, stream); break;
+                        }
+                    else
+                        switch (ctx->mode) {
+                            case PAIR_L1_F64: e = launch_stream<K_L1, 4>(ctx, b, stream); break;
+                            case PAIR_SAD_U32: e = launch_stream<K_SAD, 4>(ctx, b, stream); break;
+                            case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4>(ctx, b, stream); break;
+                            default: e = launch_stream<K_DOT, 4>(ctx, b, stream); break;
+                        }
+                }
+                if (e == hipSuccess && n_mask > 0) {
+                    PairArgs c = a;
+                    c.i_end = i_full; c.j_end = j_full;
+                    c.tiles_i = b.tiles_i; c.tiles_j = b.tiles_j;
+                    c.tiles = l_mask;
+                    c.ntiles = n_mask;
+                    e = launch_one_tile(ctx, c, 128, stream);
+                }
+                if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
+                // strips (only in a sweep's first phase: they are not split into phases)
+                int rc = HSD_OK;
+                if (a.n_phases <= 1 || a.phase == 0) {
+                    PairArgs c = a;
+                    c.phase = 0; c.n_phases = 0;
+                    if (a.sym) {
+                        if (i_full < a.i_end) {
+                            // rows of the whole tiles x the last columns (mirrored), then the corner square
+                            c.sym = 0; c.mirror = a.mirror;
+                            c.i_begin = a.i_begin; c.i_end = i_full; c.j_begin = i_full; c.j_end = a.i_end;
+                            if ((rc = launch_region(ctx, c, BT, stream, false))) return rc;
+                            c.sym = 1;
+                            c.i_begin = i_full; c.i_end = a.i_end; c.j_begin = i_full; c.j_end = a.i_end;
+                            if ((rc = launch_region(ctx, c, BT, stream, false))) return rc;
+                        }
+                    } else {
+                        if (j_full < a.j_end) {
+                            c.i_begin = a.i_begin; c.i_end = a.i_end; c.j_begin = j_full; c.j_end = a.j_end;
+                            if ((rc = launch_region(ctx, c, BT, stream, false))) return rc;
+                        }
+                        if (i_full < a.i_end) {
+                            c.i_begin = i_full; c.i_end = a.i_end; c.j_begin = a.j_begin; c.j_end = j_full;
+                            if ((rc = launch_region(ctx, c, BT, stream, false))) return rc;
+                        }
+                    }
+                }
+                return HSD_OK;
+            }
+        }
+        // (a list could not be built: fall through to the one-tile kernel over every tile)
+    }
+    if (BT == 128 && !getenv("HSD_TILE") && ctx->mode != PAIR_ZP_F64) {
         // few tiles per CU: the small tile's five workgroups per CU overlap their phases better than two large ones
         // (ER N = 10k, raw fp64 W1: 0.321 ms with 64 x 64 tiles against 0.351 ms with 128 x 128)
         const int64_t t128i = (a.i_end - a.i_begin + 127) / 128, t128j = (a.j_end - a.j_begin + 127) / 128;
@@ -1483,51 +1841,6 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
     if (a.tiles_i <= 0 || a.tiles_j <= 0) return HSD_OK;
     const int64_t nb = a.sym ? (int64_t)a.tiles_i * (a.tiles_i + 1) / 2 : (int64_t)a.tiles_i * a.tiles_j;
     if (nb > 0x7fffffff) return hsd_fail(ctx, HSD_ERR_TOO_LARGE, "too many tiles (%lld)", (long long)nb);
-    const bool part_i = (a.i_end - a.i_begin) % BT != 0, part_j = (a.j_end - a.j_begin) % BT != 0;
-    hipError_t e = hipSuccess;
-    if (nw) {
-        // interior tiles: the persistent kernel; diagonal and partial tiles: the one-tile kernel with its masked stores
-        // (the two launches write disjoint tiles; the second is tiny and runs in the tail of the first)
-        int n_in = -1, n_mask = -1;
-        const int2 *l_in = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 1, part_i, part_j, &n_in, a.phase, a.n_phases);
-        const int2 *l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 2, part_i, part_j, &n_mask, a.phase, a.n_phases);
-        if (n_in >= 0 && n_mask >= 0) {
-            const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
-            PairArgs b = a;
-            b.tile_ctr = ctx->d_tile_ctr + 8 * (a.ctr_slot & 3);
-            b.n_aux = ctx->n_seg + ((wass ? a.point != nullptr : true) ? 1 : 0);
-            // LDS budget of the persistent kernel (2 workgroups per CU): two tiles x three vectors x 2 KiB; deeper hierarchies
-            // (more than two compared histogram layers + ring 0) take the one-tile kernel for every tile
-            if (b.n_aux > 3) { n_in = 0; l_mask = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &n_mask, a.phase, a.n_phases); }
-            if (n_in > 0) {
-                b.tiles = l_in;
-                b.ntiles = n_in;
-                if (a.tau)
-                    switch (ctx->mode) {
-                        case PAIR_L1_F64: e = launch_stream<K_L1, 4, true>(ctx, b, stream); break;
-                        case PAIR_SAD_U32: e = launch_stream<K_SAD, 4, true>(ctx, b, stream); break;
-                        case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4, true>(ctx, b, stream); break;
-                        default: e = launch_stream<K_DOT, 4, true>(ctx, b, stream); break;
-                    }
-                else
-                    switch (ctx->mode) {
-                        case PAIR_L1_F64: e = launch_stream<K_L1, 4>(ctx, b, stream); break;
-                        case PAIR_SAD_U32: e = launch_stream<K_SAD, 4>(ctx, b, stream); break;
-                        case PAIR_SAD_U16: e = launch_stream<K_SAD16, 4>(ctx, b, stream); break;
-                        default: e = launch_stream<K_DOT, 4>(ctx, b, stream); break;
-                    }
-            }
-            if (e == hipSuccess && n_mask > 0) {
-                PairArgs c = a;
-                c.tiles = l_mask;
-                c.ntiles = n_mask;
-                e = launch_one_tile(ctx, c, BT, stream);
-            }
-            if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
-            return HSD_OK;
-        }
-        // (list allocation failed: fall through to the one-tile kernel over every tile)
-    }
     a.ntiles = (int)nb;
     a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, nullptr);
     if (a.n_phases > 1) {
@@ -1537,7 +1850,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream) {
         a.ntiles = cnt;
         if (cnt == 0) return HSD_OK;
     }
-    e = launch_one_tile(ctx, a, BT, stream);
+    hipError_t e = launch_one_tile(ctx, a, BT, stream);
     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
     return HSD_OK;
 }
@@ -1836,7 +2149,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `two` leaves scope
     }
     HsdSegDesc *tab = ctx->seg_tab;
-    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0, 0};
+    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0, 0, -1};
     ctx->dcols_alg = nl_hist * B;
 
     if (!use_u32 || nl_hist == 0) {
@@ -1913,63 +2226,137 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             }
         }
         const int NC = (int)cand.size();
-        std::vector<uint32_t> gmax;                             // [nl_hist][NC][ngran]
+        const int ngran16 = (int)(npad / 16);
+        std::vector<uint32_t> gmax16;                           // [nl_hist][NC][ngran16]: members above the candidate threshold, per 16-node granule
         if (rank_ok) {
             // column r >= 1 is the interval [s_{r-1}, s_r): members above theta = s_{r*-1} are those in bins >= r*
             DevTmp dcand, dabove, dgm;
             HSD_TMP_ALLOC(ctx, dcand, (size_t)NC * sizeof(int));
             HSD_TMP_ALLOC(ctx, dabove, (size_t)nl_hist * NC * npad * sizeof(uint32_t));
-            HSD_TMP_ALLOC(ctx, dgm, (size_t)nl_hist * NC * ngran * sizeof(uint32_t));
+            HSD_TMP_ALLOC(ctx, dgm, (size_t)nl_hist * NC * ngran16 * sizeof(uint32_t));
             HSD_HIP(ctx, hipMemcpyAsync(dcand.p, cand.data(), (size_t)NC * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             HSD_HIP(ctx, hipMemsetAsync(dabove.p, 0, (size_t)nl_hist * NC * npad * sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(count_above_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nl_hist), block, 0, ctx->stream, p, dcand.as<int>(), NC,
                                dabove.as<uint32_t>());
-            hipLaunchKernelGGL(granule_max_kernel, dim3((unsigned)ngran, (unsigned)(nl_hist * NC)), dim3(64), 0, ctx->stream, dabove.as<uint32_t>(), npad,
-                               ngran, dgm.as<uint32_t>());
-            gmax.resize((size_t)nl_hist * NC * ngran);
-            HSD_HIP(ctx, hipMemcpyAsync(gmax.data(), dgm.p, gmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)(nl_hist * NC)), dim3(256), 0, ctx->stream,
+                               dabove.as<uint32_t>(), npad, ngran16, dgm.as<uint32_t>());
+            gmax16.resize((size_t)nl_hist * NC * ngran16);
+            HSD_HIP(ctx, hipMemcpyAsync(gmax16.data(), dgm.p, gmax16.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // temporaries leave scope
         }
         int col = nl_hist * bin_stride;
         int list_cap = 1;
         std::vector<int> first_bin((size_t)nl_hist, 0);
-        std::vector<uint32_t> rmax_sel((size_t)nl_hist * ngran, 0u);
-        const int64_t G = (n + 63) / 64;
+        std::vector<uint32_t> rmax_sel((size_t)nl_hist * ngran, 0u), rmax16_sel((size_t)nl_hist * ngran16, 0u);
         for (int sgi = 0; sgi < nl_hist; ++sgi) {
-            tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0, 0};
+            tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0, 0, -1};
             list_cap += (bin_words + 7) / 8 + 2;        // either kernel: chunks of 32 / 16 words (uint32) or 16 / 8 columns (fp64)
-            if (!rank_ok || bin_words < 2) continue;
-            double best_cost = 0.97 * bin_words;
-            int best_q = -1, best_cap = 0;
-            std::vector<uint32_t> sorted((size_t)G);
-            for (int q = 0; q < NC; ++q) {
-                const uint32_t *gm = gmax.data() + ((size_t)sgi * NC + q) * ngran;
-                std::copy(gm, gm + G, sorted.begin());
-                std::sort(sorted.begin(), sorted.end());
-                const int low_w = vfirst[(size_t)cand[(size_t)q]] / (pack ? 2 : 1), hi_w = bin_words - low_w;
-                if (hi_w < 2) continue;
-                const int cap = (int)std::min<int64_t>(hi_w - 1, words_of(sorted.back()));
-                // E over unordered granule pairs of f(max): the k-th smallest (0-based) is the maximum of k + 1 pairs
-                long double acc = 0.0L;
-                for (int64_t k2 = 0; k2 < G; ++k2) {
-                    const int64_t wr = words_of(sorted[(size_t)k2]);
-                    acc += (long double)(wr <= cap ? wr : hi_w) * (long double)(k2 + 1);
+        }
+        // Tile order and thresholds are chosen together.  A tile side of the persistent kernel is eight 16-node granules that
+        // are consecutive in the graph's granule order; with R(t) the most members above a layer's threshold among a tile's
+        // nodes, a tile pair reads (min form)  low words + ceil(min(R_a, R_b) / 2)  rank words if that fits the cap, else
+        // the upper bin words.  For each candidate order -- the natural one and the granules sorted by one (layer, threshold)
+        // key -- every layer takes its cheapest threshold (expected words over all tile pairs, exact from the sorted tile
+        // maxima); the cheapest total wins.  A layer that does not beat its plain bin form by 3 % keeps that.
+        const int64_t G16 = n / 16;                               // whole granules
+        struct LayerPlan { int q, cap; double cost; };
+        std::vector<int32_t> best_order;
+        std::vector<LayerPlan> best_plan((size_t)nl_hist, LayerPlan{-1, 0, (double)bin_words});
+        double best_total = (double)nl_hist * bin_words;
+        bool best_sorted = false;
+        if (rank_ok && bin_words >= 2 && G16 >= 1) {
+            const char *es = getenv("HSD_GRAN_SORT");
+            const bool may_sort = !(es && atoi(es) == 0) && G16 >= 16;
+            const int64_t NT = std::max<int64_t>(1, G16 / 8);     // tiles of eight granules (a last, shorter group counts as one)
+            std::vector<int32_t> order((size_t)G16);
+            std::vector<uint32_t> tm((size_t)((G16 + 7) / 8));
+            auto plan_for = [&](const std::vector<int32_t> &ord, std::vector<LayerPlan> &plan) -> double {
+                double total = 0.0;
+                const int64_t nt = (G16 + 7) / 8;
+                for (int sgi = 0; sgi < nl_hist; ++sgi) {
+                    LayerPlan bp{-1, 0, 0.97 * bin_words};
+                    for (int q = 0; q < NC; ++q) {
+                        const int low_w = vfirst[(size_t)cand[(size_t)q]] / (pack ? 2 : 1), hi_w = bin_words - low_w;
+                        if (hi_w < 2) continue;
+                        const uint32_t *gm = gmax16.data() + ((size_t)sgi * NC + q) * ngran16;
+                        uint32_t gmx = 0;
+                        for (int64_t t = 0; t < nt; ++t) {
+                            uint32_t m = 0;
+                            for (int64_t e = 8 * t; e < std::min<int64_t>(G16, 8 * t + 8); ++e) m = std::max(m, gm[ord[(size_t)e]]);
+                            tm[(size_t)t] = m;
+                            gmx = std::max(gmx, m);
+                        }
+                        if (n % 16) gmx = std::max(gmx, gm[G16]);        // (the partial last granule: one-tile kernel only)
+                        std::sort(tm.begin(), tm.begin() + nt);
+                        const int cap = (int)std::min<int64_t>(hi_w - 1, words_of(gmx));
+                        // E over unordered tile pairs of f(min): the k-th smallest (0-based) is the minimum of nt - k pairs
+                        long double acc = 0.0L;
+                        for (int64_t k2 = 0; k2 < nt; ++k2) {
+                            int64_t wr = words_of(tm[(size_t)k2]);
+                            if (low_w + wr == 0) wr = 1;
+                            acc += (long double)(wr <= cap ? wr : hi_w) * (long double)(nt - k2);
+                        }
+                        const double cost = low_w + (double)(acc / ((long double)nt * (nt + 1) / 2));
+                        if (cost < bp.cost) bp = LayerPlan{q, cap, cost};
+                    }
+                    if (bp.q < 0) bp.cost = bin_words;
+                    plan[(size_t)sgi] = bp;
+                    total += bp.cost;
                 }
-                const double cost = low_w + (double)(acc / ((long double)G * (G + 1) / 2));
-                if (cost < best_cost) { best_cost = cost; best_q = q; best_cap = cap; }
+                return total;
+            };
+            (void)NT;
+            for (int64_t g = 0; g < G16; ++g) order[(size_t)g] = (int32_t)g;
+            std::vector<LayerPlan> plan((size_t)nl_hist);
+            best_total = plan_for(order, plan);
+            best_plan = plan;
+            best_order = order;
+            if (may_sort) {
+                for (int ks = 0; ks < nl_hist; ++ks)
+                    for (int kq = 0; kq < NC; ++kq) {
+                        const uint32_t *key = gmax16.data() + ((size_t)ks * NC + kq) * ngran16;
+                        for (int64_t g = 0; g < G16; ++g) order[(size_t)g] = (int32_t)g;
+                        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+                        const double total = plan_for(order, plan);
+                        if (total < 0.99 * best_total) { best_total = total; best_plan = plan; best_order = order; best_sorted = true; }
+                    }
             }
-            if (best_q < 0) continue;
-            const int low_w = vfirst[(size_t)cand[(size_t)best_q]] / (pack ? 2 : 1);
+        }
+        ctx->gran_order.clear();
+        if (best_sorted) ctx->gran_order = best_order;
+        int suf_rows = 1;                                         // row 0: zeros
+        for (int sgi = 0; sgi < nl_hist; ++sgi) {
+            const LayerPlan &bp = best_plan[(size_t)sgi];
+            if (bp.q < 0) continue;
+            const int low_w = vfirst[(size_t)cand[(size_t)bp.q]] / (pack ? 2 : 1);
             tab[sgi].rank_col0 = col;
             tab[sgi].rank_low = low_w;
-            tab[sgi].rank_cap = best_cap;
-            first_bin[(size_t)sgi] = cand[(size_t)best_q];
-            std::copy(gmax.data() + ((size_t)sgi * NC + best_q) * ngran, gmax.data() + ((size_t)sgi * NC + best_q + 1) * ngran,
-                      rmax_sel.begin() + (size_t)sgi * ngran);
-            col += (int)round_up(low_w + best_cap, CH);
+            tab[sgi].rank_cap = bp.cap;
+            tab[sgi].suf_row0 = suf_rows;
+            suf_rows += bp.cap + 1;
+            first_bin[(size_t)sgi] = cand[(size_t)bp.q];
+            const uint32_t *gm = gmax16.data() + ((size_t)sgi * NC + bp.q) * ngran16;
+            std::copy(gm, gm + ngran16, rmax16_sel.begin() + (size_t)sgi * ngran16);
+            for (int g = 0; g < ngran; ++g)                        // the one-tile kernel plans from 64-node granules in natural order
+                rmax_sel[(size_t)sgi * ngran + g] = std::max(std::max(gm[4 * g], gm[4 * g + 1]), std::max(gm[4 * g + 2], gm[4 * g + 3]));
+            col += (int)round_up(low_w + bp.cap, CH);
         }
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax16, (size_t)nl_hist * ngran16))) return rc;
+        ctx->ngran16 = ngran16;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_suf, (size_t)(suf_rows + 1) * npad))) return rc;
+        ctx->suf_rows = suf_rows;
+        HSD_HIP(ctx, hipMemsetAsync(ctx->d_suf, 0, (size_t)(suf_rows + 1) * npad * sizeof(uint32_t), ctx->stream));
         HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax, rmax_sel.data(), rmax_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // rmax_sel is a local
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax16, rmax16_sel.data(), rmax16_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // rmax_sel / rmax16_sel are locals
+        if (getenv("HSD_PLAN_VERBOSE")) {
+            fprintf(stderr, "[hsd plan] %s granule order, expected words per tile pair %.1f (bin form %d per layer):", best_sorted ? "sorted" : "natural", best_total,
+                    bin_words);
+            for (int sgi = 0; sgi < nl_hist; ++sgi)
+                fprintf(stderr, " layer %d: first rank bin %d, low %d, cap %d, %.1f;", sgi, first_bin[(size_t)sgi], tab[sgi].rank_low, tab[sgi].rank_cap,
+                        best_plan[(size_t)sgi].cost);
+            fprintf(stderr, "\n");
+        }
         ctx->list_cap = list_cap;
         ctx->dcols = std::max(col, CH);
         ctx->dcols_alg = nl_hist * bin_words;
@@ -2001,11 +2388,12 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         for (int sgi = 0; sgi < nl_hist; ++sgi) any_rank |= tab[sgi].rank_col0 >= 0;
         if (any_rank) {
             DevTmp dr;
-            std::vector<int> rc0((size_t)3 * nl_hist);
+            std::vector<int> rc0((size_t)4 * nl_hist);
             for (int sgi = 0; sgi < nl_hist; ++sgi) {
                 rc0[(size_t)sgi] = tab[sgi].rank_col0 < 0 ? -1 : tab[sgi].rank_col0 + tab[sgi].rank_low;
                 rc0[(size_t)nl_hist + sgi] = tab[sgi].rank_cap;
                 rc0[(size_t)2 * nl_hist + sgi] = first_bin[(size_t)sgi];
+                rc0[(size_t)3 * nl_hist + sgi] = tab[sgi].suf_row0;
                 if (tab[sgi].rank_col0 >= 0 && tab[sgi].rank_low > 0)       // the bin columns below the threshold, once more in front of the ranks
                     HSD_HIP(ctx, hipMemcpyAsync((uint32_t *)ctx->d_X + (size_t)tab[sgi].rank_col0 * npad, (uint32_t *)ctx->d_X + (size_t)tab[sgi].bin_col0 * npad,
                                                 (size_t)tab[sgi].rank_low * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2013,8 +2401,8 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             HSD_TMP_ALLOC(ctx, dr, rc0.size() * sizeof(int));
             HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), rc0.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)nl_hist);
-            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, (uint32_t *)ctx->d_X);
-            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, (uint32_t *)ctx->d_X);
+            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
+            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
         }
     }
@@ -2186,7 +2574,22 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
                      hipEventCreateWithFlags(&ctx->ev_join[t], hipEventDisableTiming) == hipSuccess;
             if (!ok) return hsd_fail(ctx, HSD_ERR_HIP, "side streams: %s", hipGetErrorString(hipGetLastError()));
         }
-        if (fork) HSD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        if (fork) {
+            // the granule lists of the three regions are built on the context's stream BEFORE the fork, so that a side stream
+            // never meets a list whose tile maxima are still being computed
+            PairArgs probe = b;
+            hsd_ctx::GranList tmp{};
+            const auto prefetch = [&](int64_t ib, int64_t ie, int64_t jb, int64_t je, int sym) {
+                probe.i_begin = ib; probe.i_end = ie; probe.j_begin = jb; probe.j_end = je; probe.sym = sym;
+                if (ie <= ib || je <= jb || !stream_waves(ctx, probe)) return;
+                (void)gran_list(ctx, ib, ib + (ie - ib) / 128 * 128, ctx->stream, &tmp);
+                if (!sym) (void)gran_list(ctx, jb, jb + (je - jb) / 128 * 128, ctx->stream, &tmp);
+            };
+            prefetch(ra, re, ra, re, 1);
+            prefetch(ra, re, 0, ra, 0);
+            prefetch(ra, re, re, n, 0);
+            HSD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        }
         if ((rc = launch_square(ctx, b, ra, re))) return rc;
         b.sym = 0; b.mirror = 0;
         const int BT = tile_edge(ctx);

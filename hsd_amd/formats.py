@@ -109,8 +109,10 @@ def read_distance(path: str, n_nodes: int) -> np.ndarray:
 # ---- labels -----------------------------------------------------------------------------------
 def read_label(path) -> dict:
     """`node label` per line, separated by one blank (behaviour of tools/dataloader.py:57-75): labels are
-    ints, node ids stay strings, reading stops at the first blank line, and a missing file is reported on
-    stdout and yields {} instead of raising."""
+    ints, node ids stay strings, reading stops at the first blank line, a missing file is reported on
+    stdout and yields {} instead of raising -- and, because the reference returns from a `finally:` block,
+    ANY error while parsing (a line with more than one blank, a label that is not an int) is swallowed and the
+    labels read so far are returned.  That quirk is kept: files the reference loads (partially) load the same here."""
     labels = {}
     if not os.path.isfile(path):
         print(f"Lable file not exist, path:{path}")
@@ -120,6 +122,9 @@ def read_label(path) -> dict:
             record = raw.strip()
             if record == "":
                 break
-            node, label = record.split(" ")
-            labels[node] = int(label)
+            try:
+                node, label = record.split(" ")
+                labels[node] = int(label)
+            except ValueError:
+                break                   # the reference's `finally: return label_dict`: partial result, no exception
     return labels

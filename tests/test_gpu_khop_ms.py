@@ -163,3 +163,22 @@ def test_ring_sizes_by_the_one_bin_sweep(engine, name, hop):
     assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
     assert np.array_equal(out["1"][0], corc.khop_sizes(g.rowptr, g.col, hop))
     assert np.array_equal(out["1"][1], out["1"][0][n // 3:n - 5])
+
+
+def test_ms_sweep_falls_back_when_the_planes_cannot_be_allocated(engine):
+    """khop.hip: if the bit-parallel sweep cannot get its planes (3 n x 512 B + ring planes) the per-source sweep takes
+    over instead of failing -- histograms and ring sizes, same counts (HSD_KHOP_MS_NOPLANES rehearses the failure)."""
+    g = _graphs()["ba5000"]
+    engine.set_graph(g.rowptr, g.col)
+    ref = _counts(engine, 3, "0")
+    sizes_ref = engine.khop_sizes(3)
+    engine.set_graph(g.rowptr, g.col)                 # drops the planes a previous test may have left
+    os.environ["HSD_KHOP_MS_NOPLANES"] = "1"
+    try:
+        got = _counts(engine, 3, "1")
+        os.environ["HSD_KHOP_MS"] = "1"
+        sizes = engine.khop_sizes(3)
+    finally:
+        os.environ.pop("HSD_KHOP_MS_NOPLANES", None)
+        os.environ.pop("HSD_KHOP_MS", None)
+    assert np.array_equal(got, ref) and np.array_equal(sizes, sizes_ref)

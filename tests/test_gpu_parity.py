@@ -245,3 +245,27 @@ def test_khop_bottom_up_expansion(engine, flag):
     support = engine.signature_support()
     for v in (0, 7, 49):
         assert np.array_equal(counts[v].astype(np.int64), nr.histogram(v, support))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,row0", [(700, 700, 0), (333, 1500, 128), (64, 64, 0), (200, 1000, 800), (129, 321, 0)])
+def test_matrix_stats_against_numpy(engine, rows, cols, row0):
+    """hsd_matrix_stats (tile-wise: every entry read once, the mirror transposed through LDS) on a block with planted
+    asymmetry and a non-zero diagonal: sum / diagonal / asymmetry of the square part / max / min against numpy."""
+    rng = np.random.default_rng(rows * 7 + cols)
+    a = rng.standard_normal((rows, cols))
+    sq = a[:, row0:row0 + rows]
+    sym = 0.5 * (sq + sq.T)                      # symmetric square part ...
+    a[:, row0:row0 + rows] = sym
+    i, j = rows // 3, rows - 2
+    a[i, row0 + j] += 0.375                      # ... with one planted asymmetric pair
+    M = engine.upload_matrix(a)
+    try:
+        s = engine.matrix_stats(M.ptr, rows, cols, M.ld, row0)
+    finally:
+        M.free()
+    sqa = a[:, row0:row0 + rows]
+    assert np.isclose(s[0], a.sum(), rtol=1e-11, atol=1e-9)
+    assert s[1] == np.abs(np.diag(sqa)).max()
+    assert s[2] == np.abs(sqa - sqa.T).max() == 0.375
+    assert s[3] == a.max() and s[4] == a.min()

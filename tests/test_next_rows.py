@@ -107,3 +107,12 @@ def test_driver_flow_on_karate(engine, tmp_path, capsys):
     psi = orc.heat_wavelets_exact(g.laplacian_dense(), s)
     ref = orc.distance_variant_b_rowquirk(psi, rings, 3)
     assert np.allclose(mats[s], ref, rtol=1e-6, atol=1e-12)
+
+
+def test_read_label_swallows_malformed_lines_like_the_reference(tmp_path):
+    # tools/dataloader.py:57-75 returns from `finally:`: a malformed line ends the read, the labels so far come back
+    p = tmp_path / "bad.label"
+    p.write_text("a 1\nb 2\nc  3\nd 4\n")          # third line has two blanks -> split(" ") yields three fields
+    assert formats.read_label(str(p)) == {"a": 1, "b": 2}
+    p.write_text("a 1\nb x\nc 3\n")
+    assert formats.read_label(str(p)) == {"a": 1}

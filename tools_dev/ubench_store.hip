@@ -3,6 +3,7 @@
 // with shape 0.)
 //   shape 0: the pair kernel's -- an instruction = 8 rows x 128 B (8 lanes x 16 B per row), direct + mirrored
 //   shape 1: row-contiguous -- an instruction = one 1-KiB row segment (64 lanes x 16 B), direct + mirrored
+//   shape 2 / 3: 2 rows x 512 B / 4 rows x 256 B (what a wave could reach by exchanging registers between lanes)
 //   hipcc -O3 --offload-arch=gfx950 tools_dev/ubench_store.hip -o build/ubench_store && build/ubench_store
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,9 +29,15 @@ __global__ __launch_bounds__(256, 2) void k(double *out, long ld, int tiles_per_
                 if (SHAPE == 0) {
                     row = i0 + (w >> 1) * 64 + 2 * ly + 16 * (r >> 1) + (r & 1); col = j0 + (w & 1) * 64 + 2 * lx + 16 * q;
                     mrow = j0 + (w & 1) * 64 + 2 * lx + 16 * (r >> 1) + (r & 1); mcol = i0 + (w >> 1) * 64 + 2 * ly + 16 * q;
-                } else {
+                } else if (SHAPE == 1) {
                     row = i0 + w * 32 + r * 4 + q; col = j0 + 2 * l;
                     mrow = j0 + w * 32 + r * 4 + q; mcol = i0 + 2 * l;
+                } else if (SHAPE == 2) {      // 2 rows x 512 B: what a wave's 64 x 64 quadrant allows after an in-register transposition
+                    row = i0 + (w >> 1) * 64 + (r * 4 + q) * 2 + (l >> 5); col = j0 + (w & 1) * 64 + 2 * (l & 31);
+                    mrow = j0 + (w & 1) * 64 + (r * 4 + q) * 2 + (l >> 5); mcol = i0 + (w >> 1) * 64 + 2 * (l & 31);
+                } else {                      // 4 rows x 256 B
+                    row = i0 + (w >> 1) * 64 + (r * 2 + (q >> 1)) * 4 + (l >> 4); col = j0 + (w & 1) * 64 + 32 * (q & 1) + 2 * (l & 15);
+                    mrow = j0 + (w & 1) * 64 + (r * 2 + (q >> 1)) * 4 + (l >> 4); mcol = i0 + (w >> 1) * 64 + 32 * (q & 1) + 2 * (l & 15);
                 }
                 gv2d *p = (gv2d *)(out + row * ld + col), *pm = (gv2d *)(out + mrow * ld + mcol);
                 if (NT) { __builtin_nontemporal_store(v, p); __builtin_nontemporal_store(v, pm); }
@@ -69,5 +76,7 @@ int main(int argc, char **argv) {
     run<0, false>("shape 0 (8 rows x 128 B), plain", out, n, d_cyc, grid, tiles);
     run<1, true>("shape 1 (1 KiB row segment), nt", out, n, d_cyc, grid, tiles);
     run<1, false>("shape 1 (1 KiB row segment), plain", out, n, d_cyc, grid, tiles);
+    run<2, true>("shape 2 (2 rows x 512 B), nt", out, n, d_cyc, grid, tiles);
+    run<3, true>("shape 3 (4 rows x 256 B), nt", out, n, d_cyc, grid, tiles);
     return 0;
 }
