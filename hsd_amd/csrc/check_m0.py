@@ -7,7 +7,10 @@ nothing of its own in M0 inside these kernels.  This script disassembles the gfx
 every pair_stream_kernel instance, asserts:
   * M0 is written only by `s_mov_b32 m0, <scalar>` and each such write is followed (s_nop aside) by a global_load_lds_dwordx4;
   * every global_load_lds_dwordx4 is preceded (s_nop aside) by such a write;
-  * no other instruction names m0 (s_movrel*, s_sendmsg, v_interp, DS with M0 ... would read a value we clobbered).
+  * no other instruction names m0 (s_movrel*, s_sendmsg, v_interp, DS with M0 ... would read a value we clobbered);
+  * the hand-issued result stores (global_store_dwordx4 with a scalar base) and the LDS-DMA loads never read a scalar
+    address register within five wait states of a v_readfirstlane / v_readlane that wrote it, and every such store is
+    followed by two wait states (its data registers may be rewritten): hazards hipcc pads only for its own instructions.
 Exit status 1 with the offending lines otherwise.  Run by __graft_entry__.build() and `make check`."""
 import os
 import re
@@ -53,6 +56,32 @@ def check(lib):
             if "pair_stream_kernel" not in fn:
                 continue
             kernels += 1
+            # hand-issued vector-memory instructions with a scalar address (LDS-DMA loads, result stores): no scalar register
+            # of the address may have been written by the vector ALU (v_readfirstlane / v_readlane) within the five
+            # preceding wait states, and a store of more than 64 bits must be followed by two wait states before anything
+            # else (its data registers may be rewritten).  hipcc pads only instructions it emitted itself.
+            for k, x in enumerate(ins):
+                op = x.split()[0]
+                if not (op.startswith("global_load_lds") or (op.startswith("global_store_dwordx4") and re.search(r"s\[\d+:\d+\]", x))):
+                    continue
+                m = re.search(r"s\[(\d+):(\d+)\]", x)
+                if not m:
+                    continue
+                addr = {f"s{r}" for r in range(int(m.group(1)), int(m.group(2)) + 1)}
+                waits, j = 0, k - 1
+                while j >= 0 and waits < 5:
+                    y = ins[j]
+                    if y.startswith("s_nop"):
+                        waits += int(y.split()[1]) + 1
+                    else:
+                        if y.startswith(("v_readfirstlane_b32", "v_readlane_b32")) and y.split()[1].rstrip(",") in addr:
+                            bad.append(f"{fn}: `{x}` reads {y.split()[1].rstrip(',')} {waits} wait states after `{y}` (needs 5)")
+                        waits += 1
+                    j -= 1
+                if op.startswith("global_store_dwordx4"):
+                    nxt = ins[k + 1] if k + 1 < len(ins) else ""
+                    if not (nxt.startswith("s_nop") and int(nxt.split()[1]) >= 1):
+                        bad.append(f"{fn}: `{x}` is not followed by `s_nop 1` (found `{nxt}`)")
             real = [x for x in ins if not x.startswith("s_nop")]
             for k, x in enumerate(real):
                 op = x.split()[0]

@@ -163,7 +163,10 @@ __device__ inline void glds16(const void *g, void *lds_wave_base) {
 __device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_addr) {
     // (M0 is a reserved register: hipcc does not accept it as a clobber.  Nothing else in pair_stream_kernel uses M0 -- DS
     // instructions do not on gfx9+, and the kernel contains no LDS-DMA builtin, s_movrel or message instruction.)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
+    // (s_nop 3, not 0: together with the s_mov that is five wait states between a vector-ALU write of the base -- hipcc reloads
+    // spilled scalars with v_readlane right in front of this -- and its use as an address: a hazard hipcc pads only for
+    // instructions it emitted itself; csrc/check_m0.py verifies the distance in the disassembly)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
 }
 
 // A 16-byte store per lane with a scalar 64-bit base and a 32-bit per-lane offset, non-temporal or plain.  (Written out:
@@ -173,10 +176,14 @@ __device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_
 // write to its data registers is a hazard the hardware does not interlock.  hipcc pads its own stores; it cannot see into
 // this one, and it does re-use the four registers it copies a non-adjacent accumulator pair into for the next store
 // (measured without the pad: one mirrored entry in ~10^5 carried its neighbour's value).
+// The leading s_nop belongs to it as well: the base may come straight out of v_readfirstlane (uniform64), and a scalar
+// register written by the vector ALU must not be read as a memory address within five wait states -- again a hazard hipcc
+// pads for its own instructions only (without it: a store through a stale base, a memory access fault).
+// csrc/check_m0.py verifies both pads in the disassembly.
 template <bool NT>
 __device__ inline void gstore16_s(uint64_t sbase, uint32_t lane_off, v2f64 val) {
-    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
+    if constexpr (NT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
 }
 
 // Stage CH columns x BT nodes of one operand: LDS image [CH][BT] of T (linear, as in memory).
@@ -245,9 +252,27 @@ __device__ inline void store2_full(gdouble *p, double v0, double v1, bool nt) {
 // and takes its sparse tail by rank.  Same integer either way, so the result is bit-identical.
 struct SegDesc : HsdSegDesc {};    // columns in words
 
+// The lanes append their segments' chunks {first column, valid | ends_segment << 8 | segment << 16} to the tile's list, the
+// LAST segment first (outer rings are the long ones: the persistent kernel lets the previous tile's result stores leave
+// beside the first segment it computes, and every kernel folds the layers in list order).  Returns in every lane the list
+// length.
+template <int CH>
+__device__ inline int emit_chunks(int nch, int col0, int words, int l, int2 *lst) {
+    int suf = nch;                                   // inclusive suffix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int dn = __shfl_down(suf, o, 64);
+        if (l + o < 64) suf += dn;
+    }
+    int2 *dst = lst + (suf - nch);
+    for (int c = 0; c < nch; ++c)
+        dst[c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+    return __shfl(suf, 0, 64);
+}
+
 // Lane l < n_seg holds segment l: choose the form of its upper part from R (members above theta, worst node of the tile
 // pair), then the lanes append their chunks {first column, valid | ends_segment << 8 | segment << 16} to the tile's list.
-// Returns the inclusive prefix of the chunk counts (lane 63: the list length).
+// Returns the list length (every lane).
 template <int CH, bool PACK>
 __device__ inline int plan_segment(const SegDesc &sd, bool active, uint32_t R, int l, int2 *lst) {
     int col0 = sd.bin_col0, words = active ? sd.bin_words : 0;
@@ -256,16 +281,7 @@ __device__ inline int plan_segment(const SegDesc &sd, bool active, uint32_t R, i
         if (wr <= sd.rank_cap) { col0 = sd.rank_col0; words = sd.rank_low + wr; }     // low bins (copy) + ranks: one contiguous range
     }
     const int nch = (words + CH - 1) / CH;
-    int pre = nch;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(pre, o, 64);
-        if (l >= o) pre += up;
-    }
-    int2 *dst = lst + (pre - nch);
-    for (int c = 0; c < nch; ++c)
-        dst[c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
-    return pre;
+    return emit_chunks<CH>(nch, col0, words, l, lst);
 }
 
 // A workgroup computes exactly one tile.
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
                 }
             }
             const int pre = plan_segment<CH, KIND == K_SAD16>(sd, active, R, l, clist);
-            if (l == 63) *nlist_p = pre;
+            if (l == 0) *nlist_p = pre;
         }
         __syncthreads();
         nchunks = __builtin_amdgcn_readfirstlane(*nlist_p);
@@ -688,16 +704,7 @@ __device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t 
     }
     if (l < 4) smeta[l] = sm;
     const int nch = (words + CH - 1) / CH;
-    int pre = nch;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(pre, o, 64);
-        if (l >= o) pre += up;
-    }
-    int2 *dst = lst + (pre - nch);
-    for (int c = 0; c < nch; ++c)
-        dst[c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
-    return pre;
+    return emit_chunks<CH>(nch, col0, words, l, lst);
 }
 
 // TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             const uint32_t RI = l < 4 ? (uint32_t)meta[ms * META + 16 + l] : 0u, RJ = l < 4 ? (uint32_t)meta[ms * META + 20 + l] : 0u;
             SegDesc sd = segd[l & 3];
             const int pre = plan_segment_min<CH, KIND == K_SAD16>(sd, l < a.n_seg, RI, RJ, l, clist + buf * a.list_cap, smeta + buf * 4);
-            if (l == 63) nlist[buf] = pre;
+            if (l == 0) nlist[buf] = pre;
         }
     };
     auto planned_chunks = [&](int buf) __attribute__((always_inline)) -> int {
@@ -925,12 +932,106 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     unsigned long long cyc_store = 0, cyc_loop = 0, cyc_epi = 0, n_tiles = 0;      // HSD_DEBUG bit 3 only
 #endif
 
+    // DEFERRED STORES (integer kinds, matrix output).  A finished tile's 64 result stores per wave do not leave in one burst
+    // behind its last chunk -- 15 k cycles in which the wave computes nothing, the kernel's largest loss at ~65 words per pair
+    // -- but in eight groups of eight beside the column trips of the NEXT tile's first segment (the long one: emit_chunks
+    // puts the last layer first).  Nothing extra is live for it: until that segment's fold the next tile only fills its
+    // integer sums, the fp64 accumulators still hold the previous tile's results, and the fold overwrites them instead of
+    // adding to them.  Whatever has not left by then goes out in front of the fold.
+    constexpr bool DEFERS = SEG && U32 && !TOPK;
+    int pend_g = 8;                                   // next store group of the previous tile (8: nothing pending)
+    int pend_ms = 0;                                  // ... its slot of the meta ring (row / column granules)
+    bool pend_mirror = false;
+    // the accumulators as register QUADRUPLES (two adjacent columns of a row): a 16-byte store takes one as it is
+    v2f64 acc2[TR][TC / 2];
+#define ACC(r, c) acc2[r][(c) >> 1][(c) & 1]
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) ACC(r, c) = 0.0;
+    // The mirrored tile has the same shape with rows and columns exchanged: its value for lane (ly, lx), slot [r][c], is this
+    // tile's slot [c][r] of lane (lx, ly).  Exchanging the accumulators that way IN PLACE (128 ds_bpermute, four temporaries)
+    // turns the mirrored stores into direct ones -- adjacent columns of a row in one quadruple again -- where copying
+    // non-adjacent pairs together costs four registers per store that the deferred stores do not have.
+    auto transpose_acc = [&]() __attribute__((always_inline)) {
+        const int lv = lane();
+        const int partner = (((lv & 7) << 3) | (lv >> 3)) << 2;
+        auto xch = [&](double v) __attribute__((always_inline)) -> double {
+            const long long b = __double_as_longlong(v);
+            const int lo = __builtin_amdgcn_ds_bpermute(partner, (int)b), hi = __builtin_amdgcn_ds_bpermute(partner, (int)(b >> 32));
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            ACC(r, r) = xch(ACC(r, r));
+#pragma unroll
+            for (int c = r + 1; c < TC; ++c) {
+                const double up = xch(ACC(c, r)), dn = xch(ACC(r, c));
+                ACC(r, c) = up;
+                ACC(c, r) = dn;
+            }
+            HSD_PIN_ORDER;
+        }
+    };
+    // One group of a tile's result stores: g < 4: rows 16 GI[g] + 2 ly + {0, 1} x all four column granules (direct);
+    // g >= 4: the same of the mirrored tile (transpose_acc must have run in between).  Scalar base per (row granule, column
+    // granule) + one 32-bit lane offset per parity, formed here from the lane id (see lane()).
+    auto store_group = [&](int g, int gms, bool gmirror) __attribute__((always_inline)) -> int {
+        int GI[4], GJ[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            GI[qq] = __builtin_amdgcn_readfirstlane(meta[gms * META + 4 * (w >> 1) + qq]);
+            GJ[qq] = __builtin_amdgcn_readfirstlane(meta[gms * META + 8 + 4 * (w & 1) + qq]);
+        }
+        // HSD_DEBUG bit 4 (measurement): every tile stores into the first granules' place -- the same store instructions
+        // without the HBM write stream (the lines stay in L2)
+        if (a.dbg & 16) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) { GI[qq] = 4 * (w >> 1) + qq; GJ[qq] = 8 + 4 * (w & 1) + qq; }
+        }
+        const int lv = lane(), lyv = lv >> 3, lxv = lv & 7;
+        const uint32_t ld8 = (uint32_t)a.ld * 8u;
+        if (g >= 4 && !gmirror) return 0;
+        auto put = [&](auto NT_) __attribute__((always_inline)) {
+            constexpr bool NTS = decltype(NT_)::value;
+            const uint32_t vd0 = (uint32_t)(2 * lyv) * ld8 + (uint32_t)(16 * lxv);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                if (g == gg) {
+                    const int64_t rowb = ((int64_t)16 * GI[gg] - a.rbase) * a.ld;
+#pragma unroll
+                    for (int par = 0; par < 2; ++par)
+#pragma unroll
+                        for (int qq = 0; qq < TC / 2; ++qq)
+                            gstore16_s<NTS>((uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + rowb + (int64_t)16 * GJ[qq])), vd0 + (par ? ld8 : 0u), acc2[2 * gg + par][qq]);
+                }
+                if (g == 4 + gg) {
+                    // (the accumulators have been exchanged into the mirrored tile's layout: its rows are the J granules)
+                    const int64_t rowb = ((int64_t)16 * GJ[gg] - a.rbase) * a.ld;
+#pragma unroll
+                    for (int par = 0; par < 2; ++par)
+#pragma unroll
+                        for (int qq = 0; qq < TC / 2; ++qq)
+                            gstore16_s<NTS>((uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + rowb + (int64_t)16 * GI[qq])), vd0 + (par ? ld8 : 0u), acc2[2 * gg + par][qq]);
+                }
+            }
+        };
+#if HSD_STAMPS
+        if (nt) put(std::true_type{}); else put(std::false_type{});       // HSD_DEBUG bit 2: plain instead of non-temporal stores
+#else
+        put(std::true_type{});
+#endif
+        return 8;
+    };
+
     while (true) {
-        double acc[TR][TC];
+        if constexpr (!DEFERS) {
 #pragma unroll
-        for (int r = 0; r < TR; ++r)
+            for (int r = 0; r < TR; ++r)
 #pragma unroll
-            for (int c = 0; c < TC; ++c) acc[r][c] = 0.0;
+                for (int c = 0; c < TC; ++c) ACC(r, c) = 0.0;
+        }
+        bool first_fold = true;                       // DEFERS: the tile's first fold overwrites the accumulators
         T part[TR][TC];
         if constexpr (SEG) {
 #pragma unroll
@@ -954,6 +1055,16 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 
         if (n0 == 0) {
             // a tile without operand chunks (no histogram layer compared): nothing below waits for its per-node vectors
+            if constexpr (DEFERS) {
+                for (; pend_g < 8; ++pend_g) {
+                    if (pend_g == 4 && pend_mirror) transpose_acc();
+                    vm_seq += store_group(pend_g, pend_ms, pend_mirror);
+                }
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) ACC(r, c) = 0.0;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wg_barrier();
         }
@@ -995,6 +1106,18 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     }
                 }
             }
+            if constexpr (DEFERS) {
+                // Half of the previous tile's results in front of each of the first two chunks: 32 store instructions fit the
+                // wave's queue of 63 vector-memory operations without blocking, and by the next chunk (>= 20 k cycles of
+                // arithmetic) they have drained.  (Beside the column trips of the inner loop instead, the loop body spills.)
+                if (pend_g < 8) {
+                    const int stop = pend_g < 4 ? 4 : 8;
+                    for (; pend_g < stop; ++pend_g) {
+                        if (pend_g == 4 && pend_mirror) transpose_acc();
+                        vm_seq += store_group(pend_g, pend_ms, pend_mirror);
+                    }
+                }
+            }
             T av[2][TR], bv[2][TC];
             auto load_ops = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1015,11 +1138,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
                     for (int cc = 0; cc < TC; ++cc) {
-                        if constexpr (KIND == K_L1) acc[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
+                        if constexpr (KIND == K_L1) ACC(r, cc) += fabs(av[buf][r] - bv[buf][cc]);
                         else if constexpr (KIND == K_SAD) part[r][cc] = __usad(av[buf][r], bv[buf][cc], part[r][cc]);
                         else if constexpr (KIND == K_SAD16) part[r][cc] = __builtin_amdgcn_sad_u16(av[buf][r], bv[buf][cc], part[r][cc]);
                         else if constexpr (KIND == K_ZP) part[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
-                        else acc[r][cc] = fma(av[buf][r], bv[buf][cc], acc[r][cc]);
+                        else ACC(r, cc) = fma(av[buf][r], bv[buf][cc], ACC(r, cc));
                     }
             };
             load_ops(0, 0);
@@ -1054,6 +1177,13 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             if constexpr (SEG) {
                 if (ends_seg) {
+                    if constexpr (DEFERS) {
+                        // whatever of the previous tile has not left yet: the fold below overwrites its values
+                        for (; pend_g < 8; ++pend_g) {
+                            if (pend_g == 4 && pend_mirror) transpose_acc();
+                            vm_seq += store_group(pend_g, pend_ms, pend_mirror);
+                        }
+                    }
                     // the layer closes: sum_c |..| / max(n_i, n_j) == sum * min(1/n_i, 1/n_j) (empty rings carry inv = 2).  Row by
                     // row, with only the column side's vector held: this is where the kernel's register demand peaks (both
                     // accumulator sets are live), and a spill here is a scratch reload that waits behind every outstanding
@@ -1082,11 +1212,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                         const T sv = row_suffix ? (T)sb[wi + 16 * (r >> 1) + (r & 1)] : (T)0;
 #pragma unroll
                         for (int cc = 0; cc < TC; ++cc) {
-                            acc[r][cc] = fma((double)(part[r][cc] + sv), fmin(vi, vj_[cc]), acc[r][cc]);
+                            ACC(r, cc) = fma((double)(part[r][cc] + sv), fmin(vi, vj_[cc]), (DEFERS && first_fold) ? 0.0 : ACC(r, cc));
                             part[r][cc] = (T)0;
                         }
                         HSD_PIN_ORDER;
                     }
+                    first_fold = false;
                 }
             }
             st ^= 1;
@@ -1111,11 +1242,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             nlist[2] = pos;
         }
-        // the inputs of the tile after next have arrived (they were requested a tile's worth of arithmetic ago): into the ring,
-        // BEFORE this tile's stores -- hipcc does not see the hand-issued stores below, and a wait for these loads behind
-        // them would be a wait for the stores
-        if (has2) park_meta(meta2, ring(ms + 2));
         wg_barrier();                                 // the stage of the last chunk is free only when every wave has consumed it
+        // The inputs of the tile after next have arrived (they were requested a tile's worth of arithmetic ago): into the ring
+        // -- behind the barrier, because the slot they take was the PREVIOUS tile's, whose deferred stores the other waves may
+        // have been issuing until their last chunk; and before anything else is requested or stored -- hipcc does not see the
+        // hand-issued operations below, and a wait for these loads behind them would be a wait for those.
+        if (has2) park_meta(meta2, ring(ms + 2));
         if (has1 && !aux1) { vm_seq += stage_aux(cur ^ 1, ring(ms + 1)); aux1 = true; }
         if (ahead1 == 0 && n1 > 0) {
             vm_seq += stage_chunk(chunk_col(cur ^ 1, 0), chunk_valid(cur ^ 1, 0), st, ring(ms + 1));
@@ -1145,8 +1277,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 const double hi_ = ax[wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
-                    if (a.hmode == 0) acc[r][cc] = (a.swap ? hj[cc] : hi_) - acc[r][cc];
-                    else acc[r][cc] = 0.5 * (hi_ + hj[cc] - acc[r][cc]);
+                    if (a.hmode == 0) ACC(r, cc) = (a.swap ? hj[cc] : hi_) - ACC(r, cc);
+                    else ACC(r, cc) = 0.5 * (hi_ + hj[cc] - ACC(r, cc));
                 }
             }
         }
@@ -1160,7 +1292,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             for (int r = 0; r < TR; ++r) {
                 const double pi = ax[wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
-                for (int cc = 0; cc < TC; ++cc) acc[r][cc] += fabs(pi - pj[cc]);
+                for (int cc = 0; cc < TC; ++cc) ACC(r, cc) += fabs(pi - pj[cc]);
             }
         }
         // ---- stores ----
@@ -1169,15 +1301,15 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         const unsigned long long c_s0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
         const bool mirror = a.mirror && !diag;
-        // this tile's granules: row / column bases of its results
-        int GI[4], GJ[4];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            GI[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 4 * (w >> 1) + qq]);
-            GJ[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 8 + 4 * (w & 1) + qq]);
-        }
         if constexpr (TOPK) {
-          if (!((a.dbg & 1) && acc[0][0] != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
+          if (!((a.dbg & 1) && ACC(0, 0) != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
+            // this tile's granules: the node ids of its rows / columns
+            int GI[4], GJ[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                GI[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 4 * (w >> 1) + qq]);
+                GJ[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 8 + 4 * (w & 1) + qq]);
+            }
             // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (a tile on the
             // diagonal holds both orientations of its pairs: row i only, and not i itself).  tau is read per tile: the host
             // tightens it between the phases of a sweep.
@@ -1192,7 +1324,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
                     const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
-                    const double v = acc[r][cc];
+                    const double v = ACC(r, cc);
                     if (v <= ti_ && i != j) {
                         const int slot = atomicAdd(a.cand_cnt + i, 1);
                         if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
@@ -1205,48 +1337,18 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             // (vm_seq stays as it is: it must remain a LOWER bound of the operations issued, and these are data dependent)
           }
-        } else if ((a.dbg & 1) && acc[0][0] != -1.0) {
+        } else if ((a.dbg & 1) && ACC(0, 0) != -1.0) {
             // ablation: no stores
+        } else if (DEFERS && has1) {
+            // the results stay in the accumulators and leave beside the next tile's first segment
+            pend_g = 0;
+            pend_ms = ms;
+            pend_mirror = mirror;
         } else {
-            // HSD_DEBUG bit 4 (measurement): every tile stores into the first granules' place -- the same store instructions
-            // without the HBM write stream (the lines stay in L2)
-            if (a.dbg & 16) {
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) { GI[qq] = 4 * (w >> 1) + qq; GJ[qq] = 8 + 4 * (w & 1) + qq; }
+            for (int g = 0; g < 8; ++g) {
+                if (g == 4 && mirror) transpose_acc();
+                vm_seq += store_group(g, ms, mirror);
             }
-            // Row 16 GI[q] + 2 ly + par, columns 16 GJ[q'] + 2 lx + {0, 1}: a scalar base per (q, q') and one 32-bit lane
-            // offset per parity -- the instruction form with a scalar address, spelled out (with vector addresses hipcc keeps
-            // 64-bit lane offsets in registers across the tile loop and spills them).  Formed per tile from the lane id (the
-            // empty asm keeps them from being hoisted out of the tile loop into four more long-lived registers).
-            const int lv = lane(), lyv = lv >> 3, lxv = lv & 7;
-            const uint32_t ld8 = (uint32_t)a.ld * 8u;
-            const uint32_t vd0 = (uint32_t)(2 * lyv) * ld8 + (uint32_t)(16 * lxv), vd1 = vd0 + ld8;
-            auto put = [&](auto NT_) __attribute__((always_inline)) {
-                constexpr bool NTS = decltype(NT_)::value;
-#pragma unroll
-                for (int r = 0; r < TR; ++r) {
-                    const int64_t rowb = ((int64_t)16 * GI[r >> 1] - a.rbase) * a.ld;
-#pragma unroll
-                    for (int qq = 0; qq < TC / 2; ++qq)
-                        gstore16_s<NTS>(reinterpret_cast<uint64_t>(a.out + rowb + (int64_t)16 * GJ[qq]), (r & 1) ? vd1 : vd0, v2f64{acc[r][2 * qq], acc[r][2 * qq + 1]});
-                }
-                if (mirror) {
-                    const uint32_t vm0 = (uint32_t)(2 * lxv) * ld8 + (uint32_t)(16 * lyv), vm1 = vm0 + ld8;
-#pragma unroll
-                    for (int cc = 0; cc < TC; ++cc) {
-                        const int64_t rowb = ((int64_t)16 * GJ[cc >> 1] - a.rbase) * a.ld;
-#pragma unroll
-                        for (int qq = 0; qq < TR / 2; ++qq)
-                            gstore16_s<NTS>(reinterpret_cast<uint64_t>(a.out + rowb + (int64_t)16 * GI[qq]), (cc & 1) ? vm1 : vm0, v2f64{acc[2 * qq][cc], acc[2 * qq + 1][cc]});
-                    }
-                }
-            };
-#if HSD_STAMPS
-            if (nt) put(std::true_type{}); else put(std::false_type{});       // HSD_DEBUG bit 2: plain instead of non-temporal stores
-#else
-            put(std::true_type{});
-#endif
-            vm_seq += mirror ? TR * TC : TR * TC / 2;
         }
 #if HSD_STAMPS
         if (a.dbg & 8) {
@@ -1275,6 +1377,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     }
 #endif
 }
+#undef ACC
 
 // ------------------------------------------------------------------------------------------
 // operand preparation (K2 finalise): counts -> bin-major operand matrices
