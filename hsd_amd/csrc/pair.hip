@@ -176,14 +176,14 @@ __device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_
 // write to its data registers is a hazard the hardware does not interlock.  hipcc pads its own stores; it cannot see into
 // this one, and it does re-use the four registers it copies a non-adjacent accumulator pair into for the next store
 // (measured without the pad: one mirrored entry in ~10^5 carried its neighbour's value).
-// The leading s_nop belongs to it as well: the base may come straight out of v_readfirstlane (uniform64), and a scalar
-// register written by the vector ALU must not be read as a memory address within five wait states -- again a hazard hipcc
-// pads for its own instructions only (without it: a store through a stale base, a memory access fault).
-// csrc/check_m0.py verifies both pads in the disassembly.
+// The caller owes it a second pad: the base comes straight out of v_readfirstlane (uniform64), and a scalar register written
+// by the vector ALU must not be read as a memory address within five wait states -- again a hazard hipcc pads for its own
+// instructions only (without it: stores through a stale base, a memory access fault).  store_group pads once per group of
+// eight stores that share a base.  csrc/check_m0.py verifies both pads in the disassembly.
 template <bool NT>
 __device__ inline void gstore16_s(uint64_t sbase, uint32_t lane_off, v2f64 val) {
-    if constexpr (NT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
-    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
 }
 
 // Stage CH columns x BT nodes of one operand: LDS image [CH][BT] of T (linear, as in memory).
@@ -974,8 +974,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         }
     };
     // One group of a tile's result stores: g < 4: rows 16 GI[g] + 2 ly + {0, 1} x all four column granules (direct);
-    // g >= 4: the same of the mirrored tile (transpose_acc must have run in between).  Scalar base per (row granule, column
-    // granule) + one 32-bit lane offset per parity, formed here from the lane id (see lane()).
+    // g >= 4: the same of the mirrored tile (transpose_acc must have run in between).  One scalar base per group + a 32-bit
+    // lane offset, formed here from the lane id (see lane()).  (Copying two accumulators of adjacent rows together for every
+    // mirrored store instead of the exchange: hipcc spills 350 registers.)
     auto store_group = [&](int g, int gms, bool gmirror) __attribute__((always_inline)) -> int {
         int GI[4], GJ[4];
 #pragma unroll
@@ -998,21 +999,24 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 if (g == gg) {
-                    const int64_t rowb = ((int64_t)16 * GI[gg] - a.rbase) * a.ld;
+                    // one scalar base per group (the row granule); the column granule goes into the 32-bit lane offset
+                    uint64_t sb = (uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + ((int64_t)16 * GI[gg] - a.rbase) * a.ld));
+                    asm volatile("s_nop 4" : "+s"(sb));          // vector-ALU-written scalar -> address: five wait states (see gstore16_s)
 #pragma unroll
                     for (int par = 0; par < 2; ++par)
 #pragma unroll
                         for (int qq = 0; qq < TC / 2; ++qq)
-                            gstore16_s<NTS>((uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + rowb + (int64_t)16 * GJ[qq])), vd0 + (par ? ld8 : 0u), acc2[2 * gg + par][qq]);
+                            gstore16_s<NTS>(sb, vd0 + (par ? ld8 : 0u) + (uint32_t)(128 * GJ[qq]), acc2[2 * gg + par][qq]);
                 }
                 if (g == 4 + gg) {
                     // (the accumulators have been exchanged into the mirrored tile's layout: its rows are the J granules)
-                    const int64_t rowb = ((int64_t)16 * GJ[gg] - a.rbase) * a.ld;
+                    uint64_t sb = (uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + ((int64_t)16 * GJ[gg] - a.rbase) * a.ld));
+                    asm volatile("s_nop 4" : "+s"(sb));
 #pragma unroll
                     for (int par = 0; par < 2; ++par)
 #pragma unroll
                         for (int qq = 0; qq < TC / 2; ++qq)
-                            gstore16_s<NTS>((uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + rowb + (int64_t)16 * GI[qq])), vd0 + (par ? ld8 : 0u), acc2[2 * gg + par][qq]);
+                            gstore16_s<NTS>(sb, vd0 + (par ? ld8 : 0u) + (uint32_t)(128 * GI[qq]), acc2[2 * gg + par][qq]);
                 }
             }
         };
@@ -1902,11 +1906,11 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     e = launch_one_tile(ctx, c, 128, stream);
                 }
                 if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
-                // strips (only in a sweep's first phase: they are not split into phases)
+                // strips (a phased sweep splits them like everything else: a strip's nodes must not meet every row of the region
+                // under their first, loose thresholds)
                 int rc = HSD_OK;
-                if (a.n_phases <= 1 || a.phase == 0) {
+                {
                     PairArgs c = a;
-                    c.phase = 0; c.n_phases = 0;
                     if (a.sym) {
                         if (i_full < a.i_end) {
                             // rows of the whole tiles x the last columns (mirrored), then the corner square
