@@ -9,10 +9,13 @@ Barabasi-Albert N = 100 000, m = 5, seed 42, K = 3, Wasserstein on per-hop degre
 symmetric fp64 matrix (80 GB) resident in HBM.  It is the largest single-GPU configuration BASELINE.json
 names, and the one its roofline target is quoted on.
 
-  primary    Variant A -- HSD.calculate_structural_distance (model/HSD.py:98-114): scipy
-             wasserstein_distance on the raw ragged ring samples, layers 0..K, fp64
-  secondary  Variant B -- HSD.parallel_calculate_HSD, the call main.py:26 makes (model/HSD.py:140-161):
-             tools.metrics.calculate_distance = zero-pad alignment + scipy, layers 0..K-1, exact integers
+  primary    Variant B -- HSD.parallel_calculate_HSD, THE CALL main.py:26 MAKES (model/HSD.py:140-161;
+             BASELINE.json's configs are "K=3 Wasserstein via main.py"): tools.metrics.calculate_distance =
+             zero-pad alignment + scipy, layers 0..K-1; exact integer arithmetic on the device
+  secondary  Variant A -- HSD.calculate_structural_distance (model/HSD.py:98-114), the reference's serial
+             self-contained form: scipy wasserstein_distance on the raw ragged ring samples, layers 0..K, fp64
+             (2 x 721 fp64 instructions per pair: bound by the vector ALU at 0.05 of the HBM roofline)
+  (rounds 1-2 printed A first; --variant A restores that.  Both variants carry the same keys.)
 
 A "step" is one pass of the all-pairs kernel over the whole matrix (this rank's row block of it) with
 the signature operands already resident in HBM.  With --gpus P > 1 the SAME matrix is row-block
@@ -71,7 +74,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", default="A", choices=["A", "B"],
+    ap.add_argument("--variant", default="B", choices=["A", "B"],
                     help="primary variant. A: scipy on raw ring samples, layers 0..K (model/HSD.py:98-114); "
                          "B: tools.metrics.calculate_distance zero-pad alignment, layers 0..K-1 (model/HSD.py:140-161)")
     ap.add_argument("--configs", default=None,
@@ -268,7 +271,7 @@ def time_pair(eng, mat, r0, r1, steps, warmup, barrier):
 def load_traffic(key):
     """HBM bytes per launch from the PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected in
     their own runs as MI355X_MICROARCH.md prescribes; summaries under profiles/).  None if that workload was not profiled."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 t = json.load(f).get(key)
@@ -277,6 +280,14 @@ def load_traffic(key):
         except OSError:
             pass
     return None
+
+
+def traffic_fields(key):
+    """roofline.traffic = HBM bytes per launch (a number, or None); roofline.traffic_detail = read / write split, kernels, source."""
+    t = load_traffic(key) if key else None
+    if isinstance(t, dict):
+        return t.get("bytes"), t
+    return t, None
 
 
 def kernel_roofline(n, rows, res, steps, metric, traffic_key=None):
@@ -294,8 +305,9 @@ def kernel_roofline(n, rows, res, steps, metric, traffic_key=None):
         instr, peak = work * 1.0, SAD_VALU_PEAK                  # one v_sad_u32 / v_sad_u16 per word pair
     else:
         instr, peak = work * (2.0 if metric == "wasserstein" else 1.0), FP64_VALU_PEAK   # sub + add|.| per column pair; KL: one FMA
+    traffic, detail = traffic_fields(traffic_key)
     return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=load_traffic(traffic_key) if traffic_key else None,
+                traffic=traffic, traffic_over_bytes_alg=round(traffic / bytes_alg, 3) if traffic else None, traffic_detail=detail,
                 kernel_ms=round(t_kernel * 1e3, 4), bytes_alg=bytes_alg,
                 valu_frac=round(instr / t_kernel / peak, 4), valu_peak_lane_instr_per_s=peak,
                 limiter="vector ALU issue" if instr / peak > bytes_alg / (HBM_PEAK_GBS * 1e9) else "HBM write stream",
@@ -375,13 +387,16 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
             # the bit-parallel sweep does not expand one BFS per source: its bytes are the frontier rows it gathers and the
             # planes it streams, (hop - 1) pulls per batch of 4096 sources, 512 B per CSR entry and 4 x 512 B per vertex
             moved = (hop - 1) * (float(g.rowptr[-1]) + 4.0 * n) * 512.0 * ((r1 - r0 + 4095) // 4096)
+            # priced by SURVEY 8(d)'s ALGORITHMIC bytes (one BFS expansion per source + the histogram rows); what the sweep
+            # itself moves (frontier planes) is the secondary figure
             sweep = {"kernel": "ms_pull / ms_hist kernels (bit-parallel k-hop sweep, 4096 sources per batch, + per-hop histograms)",
-                     "ms": round(sweep_ms, 4), "bytes_moved": moved,
-                     "achieved_GBps": round(moved / (sweep_ms * 1e-3) / 1e9, 1),
-                     "frac_of_hbm": round(moved / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "bound": "row gathers out of the Infinity Cache (about 8.6 TB/s, MI355X_MICROARCH.md)",
-                     "bytes_alg_per_source_sweep": bytes_sweep,
-                     "note": "bytes_alg_per_source_sweep is SURVEY 8(d)'s figure for one BFS per source; this sweep's own traffic is bytes_moved"}
+                     "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
+                     "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
+                     "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bytes_moved": moved, "moved_GBps": round(moved / (sweep_ms * 1e-3) / 1e9, 1),
+                     "moved_frac_of_hbm": round(moved / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bound": "row gathers out of the Infinity Cache (about 8.6 TB/s, MI355X_MICROARCH.md): bytes_moved, the planes the "
+                              "bit-parallel sweep actually streams, is 3-4x the algorithmic bytes of one BFS per source"}
         else:
             sweep = {"kernel": "khop_kernel (per-source k-hop sweep + per-hop histograms)", "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
                      "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
@@ -646,7 +661,8 @@ def run_config5(eng, cpu_seconds):
                nodes=n, edges=g.n_edge, hop=hop, scales=S, value=n / t_dev, unit="node signatures/s (8 scales x 4 rings x [sum, mean])",
                seconds=round(t_dev, 4), dtype="f64",
                roofline=dict(bound="hbm", achieved=round(bytes_alg / t_dev / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=round(bytes_alg / t_dev / 1e9 / HBM_PEAK_GBS, 4), traffic=load_traffic("ba_n50000_multihsd"),
+                             frac=round(bytes_alg / t_dev / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic_fields("ba_n50000_multihsd")[0],
+                             traffic_detail=traffic_fields("ba_n50000_multihsd")[1],
                              bytes_alg=bytes_alg, kernel="cheby_step / cheby_combine (K4): order x (12 nnz(L) per block + 24 N C)"),
                phases_s=dict(lmax_estimate_and_setup=round(t_init, 4), parallel_embed_first_call=round(t_first, 4),
                              device_recurrence_and_ring_sums_warm=round(t_dev, 4)))

@@ -110,6 +110,7 @@ def test_driver_flow_on_karate(engine, tmp_path, capsys):
 
 
 def test_read_label_swallows_malformed_lines_like_the_reference(tmp_path):
+    from hsd_amd import formats
     # tools/dataloader.py:57-75 returns from `finally:`: a malformed line ends the read, the labels so far come back
     p = tmp_path / "bad.label"
     p.write_text("a 1\nb 2\nc  3\nd 4\n")          # third line has two blanks -> split(" ") yields three fields
