@@ -952,7 +952,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     // The mirrored tile has the same shape with rows and columns exchanged: its value for lane (ly, lx), slot [r][c], is this
     // tile's slot [c][r] of lane (lx, ly).  Exchanging the accumulators that way IN PLACE (128 ds_bpermute, four temporaries)
     // turns the mirrored stores into direct ones -- adjacent columns of a row in one quadruple again -- where copying
-    // non-adjacent pairs together costs four registers per store that the deferred stores do not have.
+    // non-adjacent pairs together costs four registers per store that the deferred stores do not have (hipcc: 350 spills).
+    // (Swapping the off-diagonal elements of every 2 x 2 accumulator block inside the lane -- 16 register-pair moves, no LDS
+    // traffic -- makes the vertical pairs adjacent as well and was measured: hipcc then keeps six scratch accesses in the
+    // 512-SAD inner loop, 19.2 ms against 17.9 ms with this exchange at BA N = 100k, zero-pad.)
     auto transpose_acc = [&]() __attribute__((always_inline)) {
         const int lv = lane();
         const int partner = (((lv & 7) << 3) | (lv >> 3)) << 2;

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import weakref
 
 import numpy as np
 
@@ -41,13 +42,18 @@ class DeviceMatrix:
         self.engine, self.rows, self.cols, self.ld, self.row0 = engine, rows, cols, ld, row0
         self.ptr = None
         self.ptr = engine.malloc(rows * ld * 8)
+        engine._matrices.add(self)             # (weak: Engine.close() returns the HBM of matrices that are still alive)
 
     def free(self):
         if self.ptr:
             ptr, self.ptr = self.ptr, None
-            self.engine.free(ptr)
+            self.engine._matrices.discard(self)
+            if self.engine._ctx:
+                self.engine.free(ptr)
 
-    # a matrix is up to 80 GB of HBM: it goes back when the object dies or leaves a `with` block, not only on free()
+    # A matrix is up to 80 GB of HBM: it goes back when the object dies or leaves a `with` block, not only on free().
+    # NOTE: the release is hipFree, a device-wide synchronisation -- a finalizer that the garbage collector runs in the middle
+    # of a timed region or between asynchronous launches stalls them; hot paths (bench.py) free explicitly or use `with`.
     def __del__(self):
         try:
             if self.ptr and self.engine._ctx:
@@ -92,6 +98,7 @@ class Engine:
             raise HsdError(f"hsd_create(device={device}) failed: {self.lib.hsd_strerror(st).decode()} "
                            "(is a ROCm GPU visible? hsd_amd has no CPU fallback)")
         self._lock = threading.RLock()      # the ABI is not re-entrant per context (re-entrant lock: a DeviceMatrix finalizer may run inside _call)
+        self._matrices = weakref.WeakSet()  # live DeviceMatrix allocations (hsd_malloc is not tracked by the context itself)
         self.n = 0
         self.device = device
         self._owner = None
@@ -99,6 +106,8 @@ class Engine:
     # -- plumbing ---------------------------------------------------------
     def close(self):
         if self._ctx:
+            for m in list(self._matrices):  # matrices that outlive the engine would keep their HBM until the process exits
+                m.free()
             self.lib.hsd_destroy(self._ctx)
             self._ctx = C.c_void_p()
 

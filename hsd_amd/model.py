@@ -377,9 +377,12 @@ class MultiHSD(HSD):
         """model/multiscale_HSD.py:101-119: sum over scales of the Variant-A matrix
         (approx=True is hard-coded there, :107)."""
         if self.signature != "heat":
+            # the degree signature has no scale: the sum over the scales (:112-117) is the one Variant-A matrix added to
+            # itself len(scales) times -- computed once and added in the reference's order (same rounding as its loop)
+            one = HSD.calculate_structural_distance(self, float(self.scales[0]) if len(self.scales) else 0.0, approx)
             total = np.zeros((self.n_node, self.n_node), dtype=float)
-            for scale in self.scales:
-                total += HSD.calculate_structural_distance(self, scale, approx)
+            for _ in self.scales:
+                total += one
             return total
         # heat coefficients: one Chebyshev recurrence serves a batch of scales (as many psi matrices as a quarter of
         # the HBM holds), the per-scale matrices are added on the device, one copy to the host at the end

@@ -33,3 +33,83 @@ def test_single_rank_communicator_allgather():
         eng.close()
 
 
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["HSD_REPO"])
+import torch.distributed as dist
+import hsd_amd
+from hsd_amd import distributed as hdist
+from hsd_amd.graph import barabasi_albert
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = barabasi_albert(int(os.environ["HSD_N"]), 4, 17)
+eng = hsd_amd.Engine(0)                                   # HSD_COMM_DRYRUN: every rank on GPU 0
+eng.set_graph(g.rowptr, g.col)
+r0, r1 = hdist.init_comm(eng, dist, rank, world)           # hsd_comm_init(world = 2): the partition bench.py --gpus 2 commits
+assert (r0, r1) == hdist.shard_rows(g.n_node, world, rank) == eng.comm_shard()
+eng.signature_build_degree(3, r0, r1)                      # this rank's sources only
+hdist.allgather_signature(eng, dist, rank, world, via="host")
+for name, mode in (("B", (0, 1, 0, 2)), ("A", (0, 0, 0, 3)), ("KL", (1, 0, 0, 3))):
+    blk = hdist.distance_row_block(eng, *mode, rank, world, device_out=False)
+    np.save(os.path.join(os.environ["HSD_OUT"], f"{name}_{rank}.npy"), blk)
+    idx, val = eng.pair_topk(9, r0, r1) if name != "KL" else (None, None)
+    if idx is not None:
+        np.save(os.path.join(os.environ["HSD_OUT"], f"{name}_topk_{rank}.npy"), np.concatenate([idx.astype(np.float64), val], axis=1))
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_run_the_hip_row_block_path(tmp_path, engine):
+    """world = 2 through the code path of `bench.py --gpus 2`: hsd_comm_init(world = 2) (HSD_COMM_DRYRUN: no communicator,
+    both ranks on this box's one GPU), per-rank sweeps, hsd_amd.distributed.allgather_signature(via="host"), then each rank's
+    row block by the HIP kernels -- diagonal square + the rectangles on the side streams, persistent kernel forced -- and its
+    k-nearest rows.  The two blocks together are the one-GPU matrix, bit for bit for the Wasserstein variants."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    from hsd_amd.distributed import shard_rows
+    from hsd_amd.graph import barabasi_albert
+    n = 2 * 1408 + 37                                        # rows per rank = 1536 (whole tiles); the last block carries a strip
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSD_REPO=REPO, HSD_OUT=str(tmp_path), HSD_N=str(n), HSD_COMM_DRYRUN="1", HSD_STREAM="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(w)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    g = barabasi_albert(n, 4, 17)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    os.environ["HSD_STREAM"] = "0"
+    try:
+        for name, mode in (("B", (0, 1, 0, 2)), ("A", (0, 0, 0, 3)), ("KL", (1, 0, 0, 3))):
+            engine.pair_prepare(*mode)
+            D = engine.pair_rows_host()
+            for rank in range(2):
+                r0, r1 = shard_rows(n, 2, rank)
+                blk = np.load(tmp_path / f"{name}_{rank}.npy")
+                assert blk.shape == (r1 - r0, n)
+                if name == "KL":
+                    # a row block mirrors the upper triangle of ITS rows; KL(i||j) for the columns beyond the block is the same
+                    assert np.allclose(blk[:, r1:], D[r0:r1, r1:], rtol=1e-9, atol=1e-12)
+                    iu = np.triu_indices(r1 - r0, 1)
+                    assert np.allclose(blk[:, r0:r1][iu], D[r0:r1, r0:r1][iu], rtol=1e-9, atol=1e-12)
+                else:
+                    assert np.array_equal(blk, D[r0:r1]), (name, rank)
+                    tk = np.load(tmp_path / f"{name}_topk_{rank}.npy")
+                    idx, val = tk[:, :9].astype(np.int64), tk[:, 9:]
+                    Dm = D[r0:r1].copy()
+                    Dm[np.arange(r1 - r0), np.arange(r0, r1)] = np.inf
+                    order = np.lexsort((np.broadcast_to(np.arange(n), Dm.shape), Dm), axis=1)[:, :9]
+                    assert np.array_equal(idx, order) and np.array_equal(val, np.take_along_axis(Dm, order, 1))
+    finally:
+        os.environ.pop("HSD_STREAM", None)

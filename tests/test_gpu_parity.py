@@ -269,3 +269,22 @@ def test_matrix_stats_against_numpy(engine, rows, cols, row0):
     assert s[1] == np.abs(np.diag(sqa)).max()
     assert s[2] == np.abs(sqa - sqa.T).max() == 0.375
     assert s[3] == a.max() and s[4] == a.min()
+
+
+def test_engine_close_returns_the_hbm_of_live_matrices():
+    """DeviceMatrix allocations are tracked by their Engine: close() frees the ones still alive (hsd_destroy does not know
+    about hsd_malloc blocks), and a later free() / finalizer of such a matrix is a no-op."""
+    import hsd_amd
+    from hsd_amd.graph import erdos_renyi
+    g = erdos_renyi(300, 0.03, 3)
+    eng = hsd_amd.Engine(0)
+    eng.set_graph(g.rowptr, g.col)
+    eng.signature_build_degree(2)
+    eng.pair_prepare(0, 1, 0, 1)
+    M = eng.pair_rows_device()
+    eng.sync()
+    assert M.ptr and len(eng._matrices) == 1
+    eng.close()
+    assert M.ptr is None and len(eng._matrices) == 0
+    M.free()                                    # no-op, no call into a destroyed context
+    del M

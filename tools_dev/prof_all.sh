@@ -10,18 +10,19 @@ PROF_PASSES="trace" tools_dev/prof.sh ${tag}_bench_default > gpurun_out/prof_${t
 PROF_STEPS=3 tools_dev/prof.sh ${tag}_target --configs none > gpurun_out/prof_${tag}_target.log 2>&1 || exit 1
 PROF_STEPS=3 tools_dev/prof.sh ${tag}_config3 --workload config3 > gpurun_out/prof_${tag}_config3.log 2>&1 || exit 1
 PROF_STEPS=20 tools_dev/prof.sh ${tag}_config2 --workload config2 > gpurun_out/prof_${tag}_config2.log 2>&1 || exit 1
-# config 5: the Chebyshev kernels of MultiHSD at BA N = 20 000 under the counters (4 000 dispatches at N = 50 000 take too long
-# under PMC); the kernel-trace of the full-size run is in ${tag}_bench_default
+# config 5: the Chebyshev kernels of MultiHSD at FULL size (BA N = 50 000) under the counters, ONE impulse block (rows [0, 1024):
+# 50 cheby_step dispatches -- all 4 000 of the whole pass outlast a gpurun call under PMC); the kernel-trace of the whole
+# run is in ${tag}_bench_default
 export TMPDIR=/tmp
-R=$PWD; out=$R/gpurun_out/prof_${tag}_config5_n20000; rm -rf $out; mkdir -p $out
+R=$PWD; out=$R/gpurun_out/prof_${tag}_config5_block; rm -rf $out; mkdir -p $out
 for pass in "pmc4 FETCH_SIZE" "pmc5 WRITE_SIZE" "pmc3 GRBM_GUI_ACTIVE"; do
   set -- $pass
-  (cd /tmp && rocprofv3 --pmc $2 -d $out/$1 --output-format csv -- python3 $R/tools_dev/cfg5.py 20000 > $out/$1.log 2>&1) || { tail -5 $out/$1.log; exit 1; }
+  (cd /tmp && rocprofv3 --pmc $2 -d $out/$1 --output-format csv -- python3 $R/tools_dev/cfg5.py 50000 0 1024 > $out/$1.log 2>&1) || { tail -5 $out/$1.log; exit 1; }
 done
 python3 - $out <<'PY' | tee $out/summary.txt
 import csv, glob, collections, sys
 out = sys.argv[1]
-print("# rocprofv3 PMC passes, command: python3 tools_dev/cfg5.py 20000 (MultiHSD, BA N=20000 m=5, 8 scales, K=3, order 50)")
+print("# rocprofv3 PMC passes, command: python3 tools_dev/cfg5.py 50000 0 1024 (MultiHSD, BA N=50000 m=5, 8 scales, K=3, order 50; impulse rows [0, 1024) = one block of 1024 columns)")
 agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
 for f in sorted(glob.glob(out + '/pmc*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
