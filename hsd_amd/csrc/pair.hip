@@ -85,6 +85,7 @@ struct PairArgs {
     const uint32_t *tmax_i, *tmax_j;   // [n_seg][ntl]: most members above the segment's threshold among a list tile's nodes
     int ntl_i, ntl_j;               // list tiles per side (row stride of tmax)
     const uint32_t *suf;            // suffix sums of the rank columns [rows][npad] (HsdSegDesc::suf_row0)
+    const double *ttau_i, *ttau_j;  // k-nearest sweep: per list tile, the largest threshold among its 128 rows (this launch's tau)
     unsigned long long *stamps;     // HSD_DEBUG bit 3: per-workgroup lifetimes (measurement), else nullptr
     const double *tau;      // [n] per-node threshold, or nullptr for the normal matrix output
     int *cand_cnt;          // [n] candidates appended so far (may exceed cand_cap: overflow)
@@ -118,11 +119,23 @@ __device__ inline int64_t uniform64(int64_t v) {
 }
 
 // position t of the tile order -> tile coordinates
+template <bool SCALAR_LOAD = false>
 __device__ inline void tile_from_index(const PairArgs &a, int t, int &ti, int &tj) {
     if (a.tiles) {
         // super-tile-major order built by the host: the 2S operand blocks of an S x S group of
         // tiles are fetched from HBM once and then served by the XCD's L2
         // (the coordinates are wave-uniform: keep them in scalar registers, and everything derived from them with them)
+        if constexpr (SCALAR_LOAD) {
+            // The persistent kernel asks for a tile's coordinates between two tiles, with result stores and operand requests in
+            // flight: as a vector load (what hipcc emits next to inline asm with memory clobbers) the answer queues behind all of
+            // them and every wave waits for it with vmcnt(0).  The scalar data cache has its own counter and a few hundred cycles.
+            unsigned long long tt;
+            const int2 *p = a.tiles + __builtin_amdgcn_readfirstlane(t);
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) : "s"(p) : "memory");
+            ti = (int)(unsigned)tt;
+            tj = (int)(unsigned)(tt >> 32);
+            return;
+        }
         const int2 tt = a.tiles[__builtin_amdgcn_readfirstlane(t)];
         ti = __builtin_amdgcn_readfirstlane(tt.x);
         tj = __builtin_amdgcn_readfirstlane(tt.y);
@@ -723,10 +736,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     T *sbase = reinterpret_cast<T *>(lds_raw);
     int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
     int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths; [2]: the tile index drawn for the tile after next
-    // [3][24] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side) and, per layer
-    // segment, the most members above its threshold on the I side (16-19) and on the J side (20-23)
+    // [3][28] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side), per layer segment
+    // the most members above its threshold on the I side (16-19) and on the J side (20-23), and (k-nearest sweep) the
+    // largest threshold among the tile's rows / columns as two doubles (24-25, 26-27)
     int *meta = nlist + 4;
-    constexpr int META = 24;
+    constexpr int META = 28;
     int *smeta = meta + 3 * META;                    // [2][4]: per layer segment, suffix row | side << 30, or -1
     SegDesc *segd = reinterpret_cast<SegDesc *>(smeta + 8);      // [4]
     // auxiliary per-node vectors of the current and the next tile: [2 tiles][n_aux][I: 128 doubles | J: 128 doubles]
@@ -862,14 +876,26 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     // per-tile inputs of the plan, requested two tiles ahead by wave 0: the largest member counts of the two sides (lanes
     // 16-23: segment (l - 16) & 3, I side then J side) and the tile's granule ids (lanes 0-15)
     auto issue_meta = [&](int mti, int mtj) __attribute__((always_inline)) -> int {
+        // ONE load per lane from an address the lane selects arithmetically (every source is an array of 32-bit words; lanes
+        // with nothing to fetch re-read the first granule id): loads under per-lane conditions are merged by hipcc with a wait
+        // after each, i.e. wave 0 -- and behind the next barrier the workgroup -- would stand still for a memory latency (and
+        // for every operand request in flight: vmcnt(0)) at the top of every tile.
         int v = 0;
         if (w == 0) {
             const int l = lane();
-            if (l < 16) v = l < 8 ? a.gl_i[(int64_t)8 * mti + l] : a.gl_j[(int64_t)8 * mtj + (l - 8)];
+            const int *p = a.gl_i + (int64_t)8 * mti + (l < 8 ? l : 0);
+            if (l >= 8 && l < 16) p = a.gl_j + (int64_t)8 * mtj + (l - 8);
             if constexpr (SEG) {
-                if (l >= 16 && l < 24 && ((l - 16) & 3) < a.n_seg && a.tmax_i)
-                    v = (int)(l < 20 ? a.tmax_i[(int64_t)(l - 16) * a.ntl_i + mti] : a.tmax_j[(int64_t)(l - 20) * a.ntl_j + mtj]);
+                if (a.tmax_i) {
+                    if (l >= 16 && l < 20 && l - 16 < a.n_seg) p = reinterpret_cast<const int *>(a.tmax_i) + (int64_t)(l - 16) * a.ntl_i + mti;
+                    if (l >= 20 && l < 24 && l - 20 < a.n_seg) p = reinterpret_cast<const int *>(a.tmax_j) + (int64_t)(l - 20) * a.ntl_j + mtj;
+                }
             }
+            if constexpr (TOPK) {
+                if (l >= 24 && l < 26) p = reinterpret_cast<const int *>(a.ttau_i) + 2 * (int64_t)mti + (l - 24);
+                if (l >= 26 && l < 28) p = reinterpret_cast<const int *>(a.ttau_j) + 2 * (int64_t)mtj + (l - 26);
+            }
+            v = *p;
         }
         return v;
     };
@@ -904,15 +930,15 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 
     // ---- prologue: plan of the first tile, coordinates of the next two ----
     int ti, tj;
-    tile_from_index(a, t, ti, tj);
+    tile_from_index<true>(a, t, ti, tj);
     int cur = 0;                                      // list buffer of the tile being computed
     int ms = 0;                                       // its slot of the meta ring (next tile: ms + 1, the one after: ms + 2, mod 3)
     auto ring = [](int k) __attribute__((always_inline)) { return k >= 3 ? k - 3 : k; };
     const int t1 = t + nwx, t2 = t + 2 * nwx;
     bool has1 = t1 < hi, has2 = t2 < hi;
     int ti1 = 0, tj1 = 0, ti2 = 0, tj2 = 0;
-    if (has1) tile_from_index(a, t1, ti1, tj1);
-    if (has2) tile_from_index(a, t2, ti2, tj2);
+    if (has1) tile_from_index<true>(a, t1, ti1, tj1);
+    if (has2) tile_from_index<true>(a, t2, ti2, tj2);
     park_meta(issue_meta(ti, tj), 0);
     if (has1) park_meta(issue_meta(ti1, tj1), 1);
     plan(0, cur);
@@ -1310,6 +1336,20 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         const bool mirror = a.mirror && !diag;
         if constexpr (TOPK) {
           if (!((a.dbg & 1) && ACC(0, 0) != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
+            // Most tiles of a sweep's later phases hold no candidate at all: one comparison per value against the largest
+            // threshold of the tile's rows (and, mirrored, columns) -- two scalars that came with the tile's plan -- and a vote
+            // decide whether the per-row thresholds are fetched at all (they are global loads: a tile's worth of latency).
+            {
+                const double thr_i = __hiloint2double(__builtin_amdgcn_readfirstlane(meta[ms * META + 25]), __builtin_amdgcn_readfirstlane(meta[ms * META + 24]));
+                const double thr_j = __hiloint2double(__builtin_amdgcn_readfirstlane(meta[ms * META + 27]), __builtin_amdgcn_readfirstlane(meta[ms * META + 26]));
+                const double thr = mirror ? fmax(thr_i, thr_j) : thr_i;
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < TC; ++cc) any |= ACC(r, cc) <= thr;
+                if (__ballot(any) == 0ull) goto epilogue_done;
+            }
             // this tile's granules: the node ids of its rows / columns
             int GI[4], GJ[4];
 #pragma unroll
@@ -1344,6 +1384,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
             // (vm_seq stays as it is: it must remain a LOWER bound of the operations issued, and these are data dependent)
           }
+          epilogue_done:;
         } else if ((a.dbg & 1) && ACC(0, 0) != -1.0) {
             // ablation: no stores
         } else if (DEFERS && has1) {
@@ -1371,7 +1412,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         has1 = has2;
         const int t3 = __builtin_amdgcn_readfirstlane(nlist[2]);
         has2 = t3 >= 0;
-        if (has2) tile_from_index(a, t3, ti2, tj2);
+        if (has2) tile_from_index<true>(a, t3, ti2, tj2);
     }
     if (a.work && threadIdx.x == 0) atomicAdd(a.work, work * (unsigned long long)(BT * BT));
 #if HSD_STAMPS
@@ -1708,7 +1749,7 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     constexpr int CH = stream_chunk_cols(KIND);
     constexpr int BT = 128;
     // stages, chunk lists + lengths, granule ids + suffix rows of two tiles, per-node vectors, suffix sums
-    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 24 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
+    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 28 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
                        (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t);
     // the attribute is per device: remembered per context (one context per GPU), not per process
     size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
@@ -1807,6 +1848,19 @@ __global__ void list_tile_max_kernel(const int32_t *__restrict__ gl, int ntiles,
     tmax[k] = m;
 }
 
+// ttau[t] = largest threshold among the 128 nodes of list tile t (tau is indexed by node; nodes outside [lo, hi) have none)
+__global__ void list_tile_tau_kernel(const int32_t *__restrict__ gl, int ntiles, const double *__restrict__ tau, int64_t lo, int64_t hi,
+                                     double *__restrict__ ttau) {
+    const int t = blockIdx.x, l = threadIdx.x;            // 128 threads: one per node of the tile
+    const int64_t node = (int64_t)16 * gl[(int64_t)8 * t + (l >> 4)] + (l & 15);
+    double v = (node >= lo && node < hi) ? tau[node] : -INFINITY;
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    __shared__ double red[2];
+    if ((l & 63) == 0) red[l >> 6] = v;
+    __syncthreads();
+    if (l == 0) ttau[t] = fmax(red[0], red[1]);
+}
+
 // The granule list of the node range [begin, end) (begin on a granule, a whole number of 128-node tiles): its granules in
 // the order hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank
 // segments.  Cached per context until the operands are released; false if it cannot be built.
@@ -1822,7 +1876,7 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
     if (sorted) { for (int32_t g : ctx->gran_order) if (g >= g0 && g < g1) gl.push_back(g); }
     else for (int64_t g = g0; g < g1; ++g) gl.push_back((int32_t)g);
     if ((int64_t)gl.size() != g1 - g0 || gl.size() % 8 != 0 || gl.empty()) return false;
-    hsd_ctx::GranList L{begin, key_end, nullptr, nullptr, (int)(gl.size() / 8)};
+    hsd_ctx::GranList L{begin, key_end, nullptr, nullptr, (int)(gl.size() / 8), nullptr};
     if (hipMalloc(reinterpret_cast<void **>(&L.d_gl), gl.size() * sizeof(int32_t)) != hipSuccess) return false;
     if (hipMemcpy(L.d_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(L.d_gl); return false; }
     if (ctx->d_rmax16 && ctx->n_seg > 0) {
@@ -1832,6 +1886,11 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
         // every hsd_pair_* call joins its streams before it returns)
         hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, L.d_gl, L.ntiles, ctx->d_rmax16,
                            ctx->ngran16, ctx->n_seg, L.d_tmax);
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&L.d_ttau), (size_t)L.ntiles * sizeof(double)) != hipSuccess) {
+        (void)hipFree(L.d_gl);
+        if (L.d_tmax) (void)hipFree(L.d_tmax);
+        return false;
     }
     ctx->gran_lists.push_back(L);
     *out = L;
@@ -1883,7 +1942,16 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                 b.ntl_i = LI.ntiles; b.ntl_j = LJ.ntiles;
                 b.suf = ctx->d_suf;
                 b.stamps = nullptr;
-                if (a.tau) b.dbg &= ~8;                   // (the lifetime stamps are a matrix-launch hook)
+                if (a.tau) {
+                    b.dbg &= ~8;                          // (the lifetime stamps are a matrix-launch hook)
+                    // per-tile maxima of this launch's thresholds (they tighten between the phases of a sweep): rows [i_begin,
+                    // i_end) carry thresholds; the columns as well when the region is mirrored onto itself
+                    b.ttau_i = LI.d_ttau; b.ttau_j = LJ.d_ttau;
+                    hipLaunchKernelGGL(list_tile_tau_kernel, dim3((unsigned)LI.ntiles), dim3(128), 0, stream, LI.d_gl, LI.ntiles, a.tau, a.i_begin, a.i_end, LI.d_ttau);
+                    if (!a.sym)
+                        hipLaunchKernelGGL(list_tile_tau_kernel, dim3((unsigned)LJ.ntiles), dim3(128), 0, stream, LJ.d_gl, LJ.ntiles, a.tau,
+                                           a.mirror ? a.j_begin : (int64_t)0, a.mirror ? a.j_end : (int64_t)0, LJ.d_ttau);
+                }
                 if (n_in > 0) {
                     if (a.tau)
                         switch (ctx->mode) {
