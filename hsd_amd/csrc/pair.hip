@@ -85,7 +85,7 @@ struct PairArgs {
     const uint32_t *tmax_i, *tmax_j;   // [n_seg][ntl]: most members above the segment's threshold among a list tile's nodes
     int ntl_i, ntl_j;               // list tiles per side (row stride of tmax)
     const uint32_t *suf;            // suffix sums of the rank columns [rows][npad] (HsdSegDesc::suf_row0)
-    const double *ttau_i, *ttau_j;  // k-nearest sweep: per list tile, the largest threshold among its 128 rows (this launch's tau)
+    const double *ttau_i, *ttau_j;  // k-nearest sweep: per list granule (8 per tile), the largest threshold among its 16 rows (this launch's tau)
     unsigned long long *stamps;     // HSD_DEBUG bit 3: per-workgroup lifetimes (measurement), else nullptr
     const double *tau;      // [n] per-node threshold, or nullptr for the normal matrix output
     int *cand_cnt;          // [n] candidates appended so far (may exceed cand_cap: overflow)
@@ -736,11 +736,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     T *sbase = reinterpret_cast<T *>(lds_raw);
     int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
     int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths; [2]: the tile index drawn for the tile after next
-    // [3][28] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side), per layer segment
+    // [3][56] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side), per layer segment
     // the most members above its threshold on the I side (16-19) and on the J side (20-23), and (k-nearest sweep) the
-    // largest threshold among the tile's rows / columns as two doubles (24-25, 26-27)
+    // largest threshold within each of the tile's 8 row granules / 8 column granules as doubles (24-39, 40-55)
     int *meta = nlist + 4;
-    constexpr int META = 28;
+    constexpr int META = 56;
     int *smeta = meta + 3 * META;                    // [2][4]: per layer segment, suffix row | side << 30, or -1
     SegDesc *segd = reinterpret_cast<SegDesc *>(smeta + 8);      // [4]
     // auxiliary per-node vectors of the current and the next tile: [2 tiles][n_aux][I: 128 doubles | J: 128 doubles]
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 }
             }
             if constexpr (TOPK) {
-                if (l >= 24 && l < 26) p = reinterpret_cast<const int *>(a.ttau_i) + 2 * (int64_t)mti + (l - 24);
-                if (l >= 26 && l < 28) p = reinterpret_cast<const int *>(a.ttau_j) + 2 * (int64_t)mtj + (l - 26);
+                if (l >= 24 && l < 40) p = reinterpret_cast<const int *>(a.ttau_i) + 16 * (int64_t)mti + (l - 24);
+                if (l >= 40 && l < 56) p = reinterpret_cast<const int *>(a.ttau_j) + 16 * (int64_t)mtj + (l - 40);
             }
             v = *p;
         }
@@ -1337,17 +1337,23 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         if constexpr (TOPK) {
           if (!((a.dbg & 1) && ACC(0, 0) != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
             // Most tiles of a sweep's later phases hold no candidate at all: one comparison per value against the largest
-            // threshold of the tile's rows (and, mirrored, columns) -- two scalars that came with the tile's plan -- and a vote
-            // decide whether the per-row thresholds are fetched at all (they are global loads: a tile's worth of latency).
+            // threshold of its row granule (and, mirrored, of its column granule) -- sixteen scalars that came with the tile's
+            // plan -- and a vote decide whether the per-row thresholds are fetched at all (they are global loads: a tile's worth
+            // of latency).  Per 16-node granule, not per tile: a single hub among a tile's 256 nodes has a threshold ten times
+            // its neighbours'.
             {
-                const double thr_i = __hiloint2double(__builtin_amdgcn_readfirstlane(meta[ms * META + 25]), __builtin_amdgcn_readfirstlane(meta[ms * META + 24]));
-                const double thr_j = __hiloint2double(__builtin_amdgcn_readfirstlane(meta[ms * META + 27]), __builtin_amdgcn_readfirstlane(meta[ms * META + 26]));
-                const double thr = mirror ? fmax(thr_i, thr_j) : thr_i;
+                const double *tg = reinterpret_cast<const double *>(meta + ms * META + 24);
+                double ti4[4], tj4[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    ti4[qq] = tg[4 * (w >> 1) + qq];
+                    tj4[qq] = mirror ? tg[8 + 4 * (w & 1) + qq] : -INFINITY;
+                }
                 bool any = false;
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
-                    for (int cc = 0; cc < TC; ++cc) any |= ACC(r, cc) <= thr;
+                    for (int cc = 0; cc < TC; ++cc) any |= ACC(r, cc) <= fmax(ti4[r >> 1], tj4[cc >> 1]);
                 if (__ballot(any) == 0ull) goto epilogue_done;
             }
             // this tile's granules: the node ids of its rows / columns
@@ -1749,7 +1755,7 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     constexpr int CH = stream_chunk_cols(KIND);
     constexpr int BT = 128;
     // stages, chunk lists + lengths, granule ids + suffix rows of two tiles, per-node vectors, suffix sums
-    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 28 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
+    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 56 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
                        (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t);
     // the attribute is per device: remembered per context (one context per GPU), not per process
     size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
@@ -1848,17 +1854,17 @@ __global__ void list_tile_max_kernel(const int32_t *__restrict__ gl, int ntiles,
     tmax[k] = m;
 }
 
-// ttau[t] = largest threshold among the 128 nodes of list tile t (tau is indexed by node; nodes outside [lo, hi) have none)
-__global__ void list_tile_tau_kernel(const int32_t *__restrict__ gl, int ntiles, const double *__restrict__ tau, int64_t lo, int64_t hi,
-                                     double *__restrict__ ttau) {
-    const int t = blockIdx.x, l = threadIdx.x;            // 128 threads: one per node of the tile
-    const int64_t node = (int64_t)16 * gl[(int64_t)8 * t + (l >> 4)] + (l & 15);
-    double v = (node >= lo && node < hi) ? tau[node] : -INFINITY;
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    __shared__ double red[2];
-    if ((l & 63) == 0) red[l >> 6] = v;
-    __syncthreads();
-    if (l == 0) ttau[t] = fmax(red[0], red[1]);
+// ttau[g] = largest threshold among the 16 nodes of list granule g (eight per list tile; tau is indexed by node; nodes outside
+// [lo, hi) have none)
+__global__ void list_granule_tau_kernel(const int32_t *__restrict__ gl, int ngran, const double *__restrict__ tau, int64_t lo, int64_t hi,
+                                        double *__restrict__ ttau) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngran) return;
+    const int64_t node0 = (int64_t)16 * gl[g];
+    double v = -INFINITY;
+    for (int e = 0; e < 16; ++e)
+        if (node0 + e >= lo && node0 + e < hi) v = fmax(v, tau[node0 + e]);
+    ttau[g] = v;
 }
 
 // The granule list of the node range [begin, end) (begin on a granule, a whole number of 128-node tiles): its granules in
@@ -1887,7 +1893,7 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
         hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, L.d_gl, L.ntiles, ctx->d_rmax16,
                            ctx->ngran16, ctx->n_seg, L.d_tmax);
     }
-    if (hipMalloc(reinterpret_cast<void **>(&L.d_ttau), (size_t)L.ntiles * sizeof(double)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&L.d_ttau), (size_t)L.ntiles * 8 * sizeof(double)) != hipSuccess) {
         (void)hipFree(L.d_gl);
         if (L.d_tmax) (void)hipFree(L.d_tmax);
         return false;
@@ -1947,9 +1953,10 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     // per-tile maxima of this launch's thresholds (they tighten between the phases of a sweep): rows [i_begin,
                     // i_end) carry thresholds; the columns as well when the region is mirrored onto itself
                     b.ttau_i = LI.d_ttau; b.ttau_j = LJ.d_ttau;
-                    hipLaunchKernelGGL(list_tile_tau_kernel, dim3((unsigned)LI.ntiles), dim3(128), 0, stream, LI.d_gl, LI.ntiles, a.tau, a.i_begin, a.i_end, LI.d_ttau);
+                    hipLaunchKernelGGL(list_granule_tau_kernel, dim3((unsigned)((LI.ntiles * 8 + 255) / 256)), dim3(256), 0, stream, LI.d_gl, LI.ntiles * 8, a.tau,
+                                       a.i_begin, a.i_end, LI.d_ttau);
                     if (!a.sym)
-                        hipLaunchKernelGGL(list_tile_tau_kernel, dim3((unsigned)LJ.ntiles), dim3(128), 0, stream, LJ.d_gl, LJ.ntiles, a.tau,
+                        hipLaunchKernelGGL(list_granule_tau_kernel, dim3((unsigned)((LJ.ntiles * 8 + 255) / 256)), dim3(256), 0, stream, LJ.d_gl, LJ.ntiles * 8, a.tau,
                                            a.mirror ? a.j_begin : (int64_t)0, a.mirror ? a.j_end : (int64_t)0, LJ.d_ttau);
                 }
                 if (n_in > 0) {
