@@ -1119,8 +1119,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             if (a.dbg & 2) cvalid = 0;
             // chunk k has landed once everything older than the operations issued after its loads has retired
             // (the first chunk of a tile was waited for before the previous tile's stores went out)
-            if (!(k == 0 && first_landed)) wait_vm_young(__builtin_amdgcn_readfirstlane(vm_seq - (st ? seq_of_stage[1] : seq_of_stage[0])));
-            wg_barrier();                             // every wave's part of chunk k has landed, and chunk k - 1 is consumed
+            // (... and then the barrier at the top of the tile has already told every wave so: no second one)
+            if (!(k == 0 && first_landed)) {
+                wait_vm_young(__builtin_amdgcn_readfirstlane(vm_seq - (st ? seq_of_stage[1] : seq_of_stage[0])));
+                wg_barrier();                         // every wave's part of chunk k has landed, and chunk k - 1 is consumed
+            }
             const T *sI = sbase + st * STAGE;
             const T *sJ = sI + CH * BT;
             // the other stage is free (its chunk was consumed in the previous iteration): request the chunk after next
