@@ -1242,13 +1242,21 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                         }
                     }
                     const bool row_suffix = U32 && sm >= 0 && !(sm >> 30);
+                    if (DEFERS && first_fold) {
+                        // the previous tile's results have all been issued: the accumulators start this tile at zero (once per
+                        // tile; a select per pair in every fold costs four times as many instructions)
+#pragma unroll
+                        for (int r = 0; r < TR; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < TC; ++cc) ACC(r, cc) = 0.0;
+                    }
 #pragma unroll
                     for (int r = 0; r < TR; ++r) {
                         const double vi = ax[wi + 16 * (r >> 1) + (r & 1)];
                         const T sv = row_suffix ? (T)sb[wi + 16 * (r >> 1) + (r & 1)] : (T)0;
 #pragma unroll
                         for (int cc = 0; cc < TC; ++cc) {
-                            ACC(r, cc) = fma((double)(part[r][cc] + sv), fmin(vi, vj_[cc]), (DEFERS && first_fold) ? 0.0 : ACC(r, cc));
+                            ACC(r, cc) = fma((double)(part[r][cc] + sv), fmin(vi, vj_[cc]), ACC(r, cc));
                             part[r][cc] = (T)0;
                         }
                         HSD_PIN_ORDER;
@@ -2187,6 +2195,11 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__res
     if (lane == 0) tau[row0 + r] = last_v + fabs(last_v) * 1e-12 + slack;
 }
 
+__global__ void fill_f64_kernel(double *__restrict__ p, int64_t n, double v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ void fill_columns_kernel(double *__restrict__ S, int64_t ld, int64_t rows, int c_begin, int c_end, double v) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -2326,15 +2339,15 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     HSD_HIP(ctx, hipMemsetAsync(x0.p, 0, cnt0 * ctx->elem_bytes, ctx->stream));
     HSD_HIP(ctx, hipMemsetAsync(ntot.p, 0, (size_t)nsg * npad * sizeof(uint32_t), ctx->stream));
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_inv, (size_t)nsg * npad))) return rc;
-    {   // padded nodes: inv = 2 (treated as empty rings; never stored)
-        std::vector<double> two((size_t)nsg * npad, 2.0);
-        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_inv, two.data(), two.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    {   // padded nodes: inv = 2 (treated as empty rings; never stored) -- filled on the device (no host buffer whose lifetime an
+        // asynchronous copy would depend on; seg_begin lives in the context)
+        hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)(((size_t)nsg * npad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_inv, (int64_t)nsg * npad, 2.0);
         HSD_HIP(ctx, hipMemcpyAsync(dseg.p, ctx->seg_begin, sizeof(ctx->seg_begin), hipMemcpyHostToDevice, ctx->stream));
         if (use_u32)
             hipLaunchKernelGGL(prep_zp_kernel<uint32_t>, grid, block, 0, ctx->stream, p, x0.as<uint32_t>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
         else
             hipLaunchKernelGGL(prep_zp_kernel<double>, grid, block, 0, ctx->stream, p, x0.as<double>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `two` leaves scope
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     HsdSegDesc *tab = ctx->seg_tab;
     for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0, 0, -1};
