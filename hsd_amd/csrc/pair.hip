@@ -1250,13 +1250,20 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #pragma unroll
                             for (int cc = 0; cc < TC; ++cc) ACC(r, cc) = 0.0;
                     }
+                    if (row_suffix) {
+#pragma unroll
+                        for (int r = 0; r < TR; ++r) {
+                            const T sv = (T)sb[wi + 16 * (r >> 1) + (r & 1)];
+#pragma unroll
+                            for (int cc = 0; cc < TC; ++cc) part[r][cc] += sv;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < TR; ++r) {
                         const double vi = ax[wi + 16 * (r >> 1) + (r & 1)];
-                        const T sv = row_suffix ? (T)sb[wi + 16 * (r >> 1) + (r & 1)] : (T)0;
 #pragma unroll
                         for (int cc = 0; cc < TC; ++cc) {
-                            ACC(r, cc) = fma((double)(part[r][cc] + sv), fmin(vi, vj_[cc]), ACC(r, cc));
+                            ACC(r, cc) = fma((double)part[r][cc], fmin(vi, vj_[cc]), ACC(r, cc));
                             part[r][cc] = (T)0;
                         }
                         HSD_PIN_ORDER;
