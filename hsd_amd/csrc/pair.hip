@@ -86,6 +86,7 @@ struct PairArgs {
     int ntl_i, ntl_j;               // list tiles per side (row stride of tmax)
     const uint32_t *suf;            // suffix sums of the rank columns [rows][npad] (HsdSegDesc::suf_row0)
     const double *ttau_i, *ttau_j;  // k-nearest sweep: per list granule (8 per tile), the largest threshold among its 16 rows (this launch's tau)
+    const uint16_t *tau16;          // k-nearest sweep: this launch's thresholds as bfloat16 rounded UP, indexed like tau (persistent kernel)
     unsigned long long *stamps;     // HSD_DEBUG bit 3: per-workgroup lifetimes (measurement), else nullptr
     const double *tau;      // [n] per-node threshold, or nullptr for the normal matrix output
     int *cand_cnt;          // [n] candidates appended so far (may exceed cand_cap: overflow)
@@ -749,6 +750,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     constexpr int AUX_STRIDE = 256;                  // doubles per vector: one 1-KiB direct-to-LDS instruction per side
     // suffix sums of the longer side of a rank segment: [2 tiles][n_seg][128 uint32]
     uint32_t *sufb = reinterpret_cast<uint32_t *>(aux + 2 * a.n_aux * AUX_STRIDE);
+    // k-nearest sweep: the current tile's 128 row + 128 column thresholds as bfloat16 (rounded up: a looser threshold only appends a
+    // few more candidates) -- 512 B is what the workgroup's LDS has left, and fetching the exact fp64 thresholds from global memory
+    // in the epilogue cost a memory latency per tile (13 k cycles: every tile holds ~6 true neighbour pairs, none can be skipped)
+    uint16_t *tau16b = reinterpret_cast<uint16_t *>(sufb + 2 * a.n_seg * 128);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double *)lds_raw);
     auto lds_off = [&](const void *p) __attribute__((always_inline)) -> uint32_t {
         return lds_base + (uint32_t)(reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(lds_raw));
@@ -1077,6 +1082,18 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         if (has1) plan(ring(ms + 1), cur ^ 1);
         wg_barrier();                                 // plan of the next tile visible; every wave is done with the previous tile's LDS
         if (has1) n1 = planned_chunks(cur ^ 1);
+        if constexpr (TOPK) {
+            // this tile's thresholds (wave 3; 2 lanes per 16-node granule; the column half only where columns carry thresholds)
+            if (w == 3) {
+                const int lv = lane();
+                const int gsel = lv < 16 ? (lv >> 1) : 8 + ((lv - 16) >> 1);
+                const uint32_t toff = (uint32_t)meta[ms * META + (gsel & 15)] * 32u + 16u * (lv & 1);
+                asm volatile("" ::: "memory");
+                if (lv < (a.mirror ? 32 : 16)) glds16_s(reinterpret_cast<uint64_t>(a.tau16), toff, lds_off(tau16b));
+                asm volatile("" ::: "memory");
+                vm_seq += 1;
+            }
+        }
         // ... the inputs of the tile after it are requested now (picked up behind the chunk loop)
         const int meta2 = has2 ? issue_meta(ti2, tj2) : 0;     // (not counted in vm_seq: only operations that are certainly issued are)
         // ... and the tile after that is drawn from the XCD's counter (the answer is picked up at the end of this tile)
@@ -1353,6 +1370,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #endif
         const bool mirror = a.mirror && !diag;
         if constexpr (TOPK) {
+          // wave 3's request for the tile's thresholds is older than the next tile's first chunk, which every wave has just waited for
+          // (or nothing is left to wait for: the last tile): one barrier makes its arrival known to the other waves
+          if (!first_landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          wg_barrier();
           if (!((a.dbg & 1) && ACC(0, 0) != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
             // Most tiles of a sweep's later phases hold no candidate at all: one comparison per value against the largest
             // threshold of its row granule (and, mirrored, of its column granule) -- sixteen scalars that came with the tile's
@@ -1382,16 +1403,16 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 GJ[qq] = __builtin_amdgcn_readfirstlane(meta[ms * META + 8 + 4 * (w & 1) + qq]);
             }
             // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (a tile on the
-            // diagonal holds both orientations of its pairs: row i only, and not i itself).  tau is read per tile: the host
-            // tightens it between the phases of a sweep.
-            gcdouble *tau = (gcdouble *)a.tau;
+            // diagonal holds both orientations of its pairs: row i only, and not i itself).  The thresholds are this launch's
+            // (the host tightens them between the phases of a sweep), rounded up to bfloat16, staged with the tile.
+            auto bf = [](uint16_t h) __attribute__((always_inline)) -> double { return (double)__uint_as_float((uint32_t)h << 16); };
             double tj_[TC];
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) tj_[cc] = mirror ? tau[(int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1)] : -1.0;
+            for (int cc = 0; cc < TC; ++cc) tj_[cc] = mirror ? bf(tau16b[128 + wj + 16 * (cc >> 1) + (cc & 1)]) : -1.0;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 const int64_t i = (int64_t)16 * GI[r >> 1] + 2 * ly + (r & 1);
-                const double ti_ = tau[i];
+                const double ti_ = bf(tau16b[wi + 16 * (r >> 1) + (r & 1)]);
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
                     const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
@@ -1774,7 +1795,7 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     constexpr int BT = 128;
     // stages, chunk lists + lengths, granule ids + suffix rows of two tiles, per-node vectors, suffix sums
     const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 56 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
-                       (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t);
+                       (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t) + (TOPK ? 512 : 0);
     // the attribute is per device: remembered per context (one context per GPU), not per process
     size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
     if (lds > attr_lds) {
@@ -1870,6 +1891,18 @@ __global__ void list_tile_max_kernel(const int32_t *__restrict__ gl, int ntiles,
     uint32_t m = 0;
     for (int e = 0; e < 8; ++e) m = max(m, rmax16[(int64_t)s * ngran16 + gl[(int64_t)8 * t + e]]);
     tmax[k] = m;
+}
+
+// tau16[i] = tau[i] rounded UP to bfloat16 (tau >= 0), i in [lo, hi)
+__global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, int64_t hi, uint16_t *__restrict__ tau16) {
+    const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const double x = tau[i];
+    float f = (float)x;
+    if ((double)f < x) f = nextafterf(f, INFINITY);
+    uint32_t b = __float_as_uint(f) >> 16;
+    if (__uint_as_float(b << 16) < f) ++b;             // (positive values: the truncated pattern is below, the next one at or above)
+    tau16[i] = (uint16_t)b;
 }
 
 // ttau[g] = largest threshold among the 16 nodes of list granule g (eight per list tile; tau is indexed by node; nodes outside
@@ -1971,6 +2004,8 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     // per-tile maxima of this launch's thresholds (they tighten between the phases of a sweep): rows [i_begin,
                     // i_end) carry thresholds; the columns as well when the region is mirrored onto itself
                     b.ttau_i = LI.d_ttau; b.ttau_j = LJ.d_ttau;
+                    hipLaunchKernelGGL(tau_bf16_up_kernel, dim3((unsigned)((a.i_end - a.i_begin + 255) / 256)), dim3(256), 0, stream, a.tau, a.i_begin, a.i_end,
+                                       const_cast<uint16_t *>(a.tau16));
                     hipLaunchKernelGGL(list_granule_tau_kernel, dim3((unsigned)((LI.ntiles * 8 + 255) / 256)), dim3(256), 0, stream, LI.d_gl, LI.ntiles * 8, a.tau,
                                        a.i_begin, a.i_end, LI.d_ttau);
                     if (!a.sym)
@@ -2914,6 +2949,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
         const size_t oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
         const size_t oVal = carve((size_t)rows * cap * sizeof(double)), oOi = carve((size_t)rows * k * sizeof(int));
         const size_t oOv = carve((size_t)rows * k * sizeof(double));
+        const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64);
         if (ctx->scratch_bytes < off) {
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -2955,6 +2991,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
             PairArgs b = a;
             b.out = nullptr; b.ld = 0;
             b.tau = d_tau - r0; b.cand_cnt = d_cnt - r0; b.cand_idx = d_idx - r0 * cap; b.cand_val = d_val - r0 * cap; b.cand_cap = (int)cap;
+            b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16) - r0;
             b.phase = ph; b.n_phases = n_phases;
             b.j_begin = r0; b.j_end = r1; b.sym = 1; b.mirror = 1; b.swap = 0;
             const int BT = tile_edge(ctx);
