@@ -31,6 +31,9 @@ namespace {
 #ifndef HSD_PIN
 #define HSD_PIN 1
 #endif
+#ifndef HSD_ABLATE
+#define HSD_ABLATE 0            // measurement builds only: bit 0: the mirrored half without the accumulator exchange (wrong results)
+#endif
 #ifndef HSD_STAMPS
 #define HSD_STAMPS 0                // 1: the persistent kernel carries its in-kernel cycle stamps (HSD_DEBUG bit 3) and the plain-store switch
 #endif                              //    (bit 2) -- a measurement build: a dozen scalar registers the product kernel needs for itself
@@ -382,6 +385,18 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
     for (int r = 0; r < TR; ++r)
 #pragma unroll
         for (int c = 0; c < TC; ++c) acc[r][c] = 0.0;
+    if (SEG && gpoint) {
+        // layer kinds: the accumulators start at the ring-0 term (the persistent kernel's rule: same bits)
+        double pj[TC];
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) pj[cc] = gpoint[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const double pi = gpoint[i0 + wi + 16 * (r >> 1) + (r & 1)];
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) acc[r][cc] = fabs(pi - pj[cc]);
+        }
+    }
     T part[TR][TC];
     if constexpr (SEG) {
 #pragma unroll
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
             }
         }
     }
-    if (gpoint) {
+    if (!SEG && gpoint) {
         double pj[TC];
 #pragma unroll
         for (int cc = 0; cc < TC; ++cc) pj[cc] = gpoint[j0 + wj + 16 * (cc >> 1) + (cc & 1)];
@@ -980,37 +995,33 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     for (int r = 0; r < TR; ++r)
 #pragma unroll
         for (int c = 0; c < TC; ++c) ACC(r, c) = 0.0;
-    // The mirrored tile has the same shape with rows and columns exchanged: its value for lane (ly, lx), slot [r][c], is this
-    // tile's slot [c][r] of lane (lx, ly).  Exchanging the accumulators that way IN PLACE (128 ds_bpermute, four temporaries)
-    // turns the mirrored stores into direct ones -- adjacent columns of a row in one quadruple again -- where copying
-    // non-adjacent pairs together costs four registers per store that the deferred stores do not have (hipcc: 350 spills).
-    // (Swapping the off-diagonal elements of every 2 x 2 accumulator block inside the lane -- 16 register-pair moves, no LDS
-    // traffic -- makes the vertical pairs adjacent as well and was measured: hipcc then keeps six scratch accesses in the
-    // 512-SAD inner loop, 19.2 ms against 17.9 ms with this exchange at BA N = 100k, zero-pad.)
+    // The mirrored tile: entry (j, i) = this tile's (i, j).  A lane's 8 x 8 block holds rows 2 ly + {0, 1} + 16 a and columns
+    // 2 lx + {0, 1} + 16 q, so the two ROWS of a 2 x 2 sub-block are adjacent columns of the mirrored matrix: exchanging the
+    // off-diagonal elements of every 2 x 2 sub-block inside the lane (ACC(2a, 2q+1) <-> ACC(2a+1, 2q): 32 v_swap_b32, no
+    // temporaries, no LDS) leaves in quadruple [2a + p][q] the mirrored row of column 2q + p with its columns 2a, 2a + 1 --
+    // a 16-byte store again, with lx choosing the row and ly the 16 bytes of the line.  (Round 3 first exchanged whole blocks
+    // between lane (ly, lx) and lane (lx, ly): 128 ds_bpermute per tile, 1.1 of 16.6 ms at BA N = 100k by a build without it.
+    // The same swap written in C++ made hipcc keep six scratch accesses in the 512-SAD inner loop.)
     auto transpose_acc = [&]() __attribute__((always_inline)) {
-        const int lv = lane();
-        const int partner = (((lv & 7) << 3) | (lv >> 3)) << 2;
-        auto xch = [&](double v) __attribute__((always_inline)) -> double {
-            const long long b = __double_as_longlong(v);
-            const int lo = __builtin_amdgcn_ds_bpermute(partner, (int)b), hi = __builtin_amdgcn_ds_bpermute(partner, (int)(b >> 32));
-            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-        };
+#if HSD_ABLATE & 1
+        return;                                       // -DHSD_ABLATE=1 (measurement build): the mirrored half without the exchange
+#endif
 #pragma unroll
-        for (int r = 0; r < TR; ++r) {
-            ACC(r, r) = xch(ACC(r, r));
+        for (int aa = 0; aa < TR / 2; ++aa)
 #pragma unroll
-            for (int c = r + 1; c < TC; ++c) {
-                const double up = xch(ACC(c, r)), dn = xch(ACC(r, c));
-                ACC(r, c) = up;
-                ACC(c, r) = dn;
+            for (int qq = 0; qq < TC / 2; ++qq) {
+                const long long bx = __double_as_longlong(ACC(2 * aa, 2 * qq + 1)), by = __double_as_longlong(ACC(2 * aa + 1, 2 * qq));
+                int xl = (int)bx, xh = (int)(bx >> 32), yl = (int)by, yh = (int)(by >> 32);
+                asm("v_swap_b32 %0, %1" : "+v"(xl), "+v"(yl));
+                asm("v_swap_b32 %0, %1" : "+v"(xh), "+v"(yh));
+                ACC(2 * aa, 2 * qq + 1) = __longlong_as_double(((long long)xh << 32) | (unsigned int)xl);
+                ACC(2 * aa + 1, 2 * qq) = __longlong_as_double(((long long)yh << 32) | (unsigned int)yl);
             }
-            HSD_PIN_ORDER;
-        }
     };
     // One group of a tile's result stores: g < 4: rows 16 GI[g] + 2 ly + {0, 1} x all four column granules (direct);
-    // g >= 4: the same of the mirrored tile (transpose_acc must have run in between).  One scalar base per group + a 32-bit
-    // lane offset, formed here from the lane id (see lane()).  (Copying two accumulators of adjacent rows together for every
-    // mirrored store instead of the exchange: hipcc spills 350 registers.)
+    // g >= 4: rows 16 GJ[g - 4] + 2 lx + {0, 1} of the mirrored tile x all four row granules (transpose_acc must have run in
+    // between).  One scalar base per group + a 32-bit lane offset, formed here from the lane id (see lane()).  (Copying two
+    // accumulators of adjacent rows together for every mirrored store instead of the exchange: hipcc spills 350 registers.)
     auto store_group = [&](int g, int gms, bool gmirror) __attribute__((always_inline)) -> int {
         int GI[4], GJ[4];
 #pragma unroll
@@ -1043,14 +1054,16 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                             gstore16_s<NTS>(sb, vd0 + (par ? ld8 : 0u) + (uint32_t)(128 * GJ[qq]), acc2[2 * gg + par][qq]);
                 }
                 if (g == 4 + gg) {
-                    // (the accumulators have been exchanged into the mirrored tile's layout: its rows are the J granules)
+                    // mirrored rows 16 GJ[gg] + 2 lx + par (transpose_acc has run): quadruple [2 aa + par][gg] holds that row's
+                    // columns 16 GI[aa] + 2 ly + {0, 1}
                     uint64_t sb = (uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + ((int64_t)16 * GJ[gg] - a.rbase) * a.ld));
                     asm volatile("s_nop 4" : "+s"(sb));
+                    const uint32_t vdm = (uint32_t)(2 * lxv) * ld8 + (uint32_t)(16 * lyv);
 #pragma unroll
                     for (int par = 0; par < 2; ++par)
 #pragma unroll
-                        for (int qq = 0; qq < TC / 2; ++qq)
-                            gstore16_s<NTS>(sb, vd0 + (par ? ld8 : 0u) + (uint32_t)(128 * GI[qq]), acc2[2 * gg + par][qq]);
+                        for (int aa = 0; aa < TR / 2; ++aa)
+                            gstore16_s<NTS>(sb, vdm + (par ? ld8 : 0u) + (uint32_t)(128 * GI[aa]), acc2[2 * aa + par][gg]);
                 }
             }
         };
@@ -1062,21 +1075,45 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         return 8;
     };
 
+    // a layer's integer sums: zero here, and every fold leaves them at zero again (every layer closes with a fold)
+    T part[TR][TC];
+    if constexpr (SEG) {
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) part[r][c] = (T)0;
+    }
+    // A tile's accumulators start at the ring-0 term |p_i - p_j| (or zero): one subtraction and a sign mask per pair instead of
+    // zeroing them and adding the term at the end.  Layer kinds: at the tile's first fold (every kernel of those kinds starts
+    // from the same value, so they stay bit-identical to each other).
+    auto init_acc = [&](int buf) __attribute__((always_inline)) {
+        if (gpoint) {
+            double pj[TC];
+            const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
+            const double *ax = aux + (buf * a.n_aux + a.n_seg) * AUX_STRIDE;
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) pj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const double pi = ax[wi + 16 * (r >> 1) + (r & 1)];
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) ACC(r, cc) = fabs(pi - pj[cc]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) ACC(r, cc) = 0.0;
+        }
+    };
     while (true) {
-        if constexpr (!DEFERS) {
+        if constexpr (!SEG) {
 #pragma unroll
             for (int r = 0; r < TR; ++r)
 #pragma unroll
                 for (int c = 0; c < TC; ++c) ACC(r, c) = 0.0;
         }
-        bool first_fold = true;                       // DEFERS: the tile's first fold overwrites the accumulators
-        T part[TR][TC];
-        if constexpr (SEG) {
-#pragma unroll
-            for (int r = 0; r < TR; ++r)
-#pragma unroll
-                for (int c = 0; c < TC; ++c) part[r][c] = (T)0;
-        }
+        bool first_fold = true;                       // the tile's first fold sets the accumulators (init_acc)
         // the next tile's plan: its inputs were parked in the ring during the previous tile
         int n1 = 0;
         if (has1) plan(ring(ms + 1), cur ^ 1);
@@ -1110,13 +1147,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     if (pend_g == 4 && pend_mirror) transpose_acc();
                     vm_seq += store_group(pend_g, pend_ms, pend_mirror);
                 }
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < TC; ++c) ACC(r, c) = 0.0;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wg_barrier();
+            if constexpr (SEG) init_acc(cur);
         }
 #if HSD_STAMPS
         const unsigned long long c_l0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1159,18 +1193,6 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     }
                 }
             }
-            if constexpr (DEFERS) {
-                // Half of the previous tile's results in front of each of the first two chunks: 32 store instructions fit the
-                // wave's queue of 63 vector-memory operations without blocking, and by the next chunk (>= 20 k cycles of
-                // arithmetic) they have drained.  (Beside the column trips of the inner loop instead, the loop body spills.)
-                if (pend_g < 8) {
-                    const int stop = pend_g < 4 ? 4 : 8;
-                    for (; pend_g < stop; ++pend_g) {
-                        if (pend_g == 4 && pend_mirror) transpose_acc();
-                        vm_seq += store_group(pend_g, pend_ms, pend_mirror);
-                    }
-                }
-            }
             T av[2][TR], bv[2][TC];
             auto load_ops = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1203,13 +1225,24 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             constexpr int UNR = sizeof(T) == 4 ? 8 : HSD_F64_UNROLL;
 #pragma unroll 1
             for (; UNR > 2 && c + UNR <= cvalid; c += UNR) {        // straight-line body: counted LDS waits (see pair_kernel)
+                if constexpr (DEFERS) {
+                    // one group of the previous tile's results in front of every 8-word trip (~2 100 cycles of arithmetic apart:
+                    // the store path never sees a burst; two bursts of 32 in front of the first two chunks: +0.25 of 16.7 ms)
+                    if (pend_g < 8) {
+                        if (pend_g == 4 && pend_mirror) transpose_acc();
+                        vm_seq += store_group(pend_g, pend_ms, pend_mirror);
+                        ++pend_g;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < UNR; u += 2) {
-                    load_ops(min(c + u + 1, CH - 1), 1);
+                    // (no clamp: the word after a chunk's last is read and never used -- the J block / the next stage / the
+                    // tile lists lie there, inside the workgroup's LDS -- and the trip's eight words share one address register)
+                    load_ops(c + u + 1, 1);
                     HSD_PIN_ORDER;
                     compute(0);
                     HSD_PIN_ORDER;
-                    load_ops(min(c + u + 2, CH - 1), 0);
+                    load_ops(c + u + 2, 0);
                     HSD_PIN_ORDER;
                     compute(1);
                     HSD_PIN_ORDER;
@@ -1217,12 +1250,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             }
 #pragma unroll 1
             for (; c < cvalid; c += 2) {
-                load_ops(min(c + 1, CH - 1), 1);
+                load_ops(c + 1, 1);
                 HSD_PIN_ORDER;
                 compute(0);
                 HSD_PIN_ORDER;
                 if (c + 1 < cvalid) {
-                    load_ops(min(c + 2, CH - 1), 0);
+                    load_ops(c + 2, 0);
                     HSD_PIN_ORDER;
                     compute(1);
                     HSD_PIN_ORDER;
@@ -1259,14 +1292,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                         }
                     }
                     const bool row_suffix = U32 && sm >= 0 && !(sm >> 30);
-                    if (DEFERS && first_fold) {
-                        // the previous tile's results have all been issued: the accumulators start this tile at zero (once per
-                        // tile; a select per pair in every fold costs four times as many instructions)
-#pragma unroll
-                        for (int r = 0; r < TR; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < TC; ++cc) ACC(r, cc) = 0.0;
-                    }
+                    // (deferred stores: the previous tile's results have all been issued by now)
+                    if (first_fold) init_acc(cur);
                     if (row_suffix) {
 #pragma unroll
                         for (int r = 0; r < TR; ++r) {
@@ -1350,7 +1377,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 }
             }
         }
-        if (gpoint) {
+        if (!SEG && gpoint) {
             double pj[TC];
             const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
             const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;

@@ -35,6 +35,25 @@ __global__ __launch_bounds__(256, 2) void k(double *out, long ld, int tiles_per_
                 } else if (SHAPE == 2) {      // 2 rows x 512 B: what a wave's 64 x 64 quadrant allows after an in-register transposition
                     row = i0 + (w >> 1) * 64 + (r * 4 + q) * 2 + (l >> 5); col = j0 + (w & 1) * 64 + 2 * (l & 31);
                     mrow = j0 + (w & 1) * 64 + (r * 4 + q) * 2 + (l >> 5); mcol = i0 + (w >> 1) * 64 + 2 * (l & 31);
+                } else if (SHAPE == 6) {      // shape 0's lines with the lane roles exchanged: lx picks the row, ly the 16 bytes of the line
+                    row = i0 + (w >> 1) * 64 + 2 * lx + 16 * (r >> 1) + (r & 1); col = j0 + (w & 1) * 64 + 2 * ly + 16 * q;
+                    mrow = j0 + (w & 1) * 64 + 2 * lx + 16 * (r >> 1) + (r & 1); mcol = i0 + (w >> 1) * 64 + 2 * ly + 16 * q;
+                } else if (SHAPE == 7) {      // direct as shape 0, mirrored as shape 6 (the in-lane 2 x 2 swap of the pair kernel)
+                    row = i0 + (w >> 1) * 64 + 2 * ly + 16 * (r >> 1) + (r & 1); col = j0 + (w & 1) * 64 + 2 * lx + 16 * q;
+                    mrow = j0 + (w & 1) * 64 + 2 * lx + 16 * (r >> 1) + (r & 1); mcol = i0 + (w >> 1) * 64 + 2 * ly + 16 * q;
+                } else if (SHAPE == 8) {      // lane bits interleaved (x0 y0 x1 y1 x2 y2): both halves see 2 rows x 32 B per lane quad
+                    const int ex = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4), ey = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);
+                    row = i0 + (w >> 1) * 64 + 2 * ey + 16 * (r >> 1) + (r & 1); col = j0 + (w & 1) * 64 + 2 * ex + 16 * q;
+                    mrow = j0 + (w & 1) * 64 + 2 * ex + 16 * (r >> 1) + (r & 1); mcol = i0 + (w >> 1) * 64 + 2 * ey + 16 * q;
+                } else if (SHAPE == 4) {      // 2 rows x four 128-B lines at scattered granule columns (granule-composed tiles after a
+                                              // register exchange of two row bits against the column-granule index)
+                    const int g = (l >> 3) & 3, rr2 = l >> 5;
+                    row = i0 + (w >> 1) * 64 + (r * 4 + q) * 2 + rr2; col = j0 + (w & 1) * 64 + ((g * 37 + r) % 61) * 16 + 2 * (l & 7);
+                    mrow = j0 + (w & 1) * 64 + (r * 4 + q) * 2 + rr2; mcol = i0 + (w >> 1) * 64 + ((g * 37 + r) % 61) * 16 + 2 * (l & 7);
+                } else if (SHAPE == 5) {      // 4 rows x two scattered 128-B lines
+                    const int g = (l >> 3) & 1, rr4 = l >> 4;
+                    row = i0 + (w >> 1) * 64 + (r * 2 + (q >> 1)) * 4 + rr4; col = j0 + (w & 1) * 64 + (((g + 2 * (q & 1)) * 37 + r) % 61) * 16 + 2 * (l & 7);
+                    mrow = j0 + (w & 1) * 64 + (r * 2 + (q >> 1)) * 4 + rr4; mcol = i0 + (w >> 1) * 64 + (((g + 2 * (q & 1)) * 37 + r) % 61) * 16 + 2 * (l & 7);
                 } else {                      // 4 rows x 256 B
                     row = i0 + (w >> 1) * 64 + (r * 2 + (q >> 1)) * 4 + (l >> 4); col = j0 + (w & 1) * 64 + 32 * (q & 1) + 2 * (l & 15);
                     mrow = j0 + (w & 1) * 64 + (r * 2 + (q >> 1)) * 4 + (l >> 4); mcol = i0 + (w >> 1) * 64 + 32 * (q & 1) + 2 * (l & 15);
@@ -78,5 +97,10 @@ int main(int argc, char **argv) {
     run<1, false>("shape 1 (1 KiB row segment), plain", out, n, d_cyc, grid, tiles);
     run<2, true>("shape 2 (2 rows x 512 B), nt", out, n, d_cyc, grid, tiles);
     run<3, true>("shape 3 (4 rows x 256 B), nt", out, n, d_cyc, grid, tiles);
+    run<6, true>("shape 6 (shape 0, lane roles exchanged), nt", out, n, d_cyc, grid, tiles);
+    run<7, true>("shape 7 (direct 0 + mirrored 6), nt", out, n, d_cyc, grid, tiles);
+    run<8, true>("shape 8 (lane bits interleaved), nt", out, n, d_cyc, grid, tiles);
+    run<4, true>("shape 4 (2 rows x 4 scattered lines), nt", out, n, d_cyc, grid, tiles);
+    run<5, true>("shape 5 (4 rows x 2 scattered lines), nt", out, n, d_cyc, grid, tiles);
     return 0;
 }
