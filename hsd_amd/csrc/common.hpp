@@ -38,7 +38,15 @@ constexpr int HSD_LCHUNK = 64;     // CSR entries per chunk of a long Laplacian 
 // suf_row0 >= 0: rows [suf_row0, suf_row0 + rank_cap] of the suffix matrix hold, for word index w, the sum of the layer's rank
 // values from word w on (persistent kernel, "min form": a tile pair reads only as many rank words as the SHORTER of its two
 // sides needs and takes the rest of the longer side from this sum).
-struct HsdSegDesc { int bin_col0, bin_words, rank_col0, rank_low, rank_cap, suf_row0; };
+// r8_col0 >= 0 (packed uint16 layers, persistent kernel): a third range holds the rank-form range once more with its SMALL values as
+// uint8 (four columns per word, one v_sad_u8): [first r8_b16 low-bin words | first r8_r16 rank words] as uint16 (r8_k16 words
+// together), then the remaining low-bin words and the remaining rank words two-into-one as uint8 (r8_fixed words before the rank
+// tail, whose length follows the tile pair like the rank words; at most r8_cap).  A tile pair may read it when no node of its two
+// sides holds a value >= 256 in a column that is uint8 there (bit 31 of the per-granule maxima d_rmax16 marks granules that do).
+struct HsdSegDesc {
+    int bin_col0, bin_words, rank_col0, rank_low, rank_cap, suf_row0;
+    int r8_col0 = -1, r8_fixed = 0, r8_k16 = 0, r8_r16 = 0, r8_cap = 0, r8_pad = 0;
+};
 
 struct hsd_ctx {
     int device = 0;

@@ -273,8 +273,10 @@ struct SegDesc : HsdSegDesc {};    // columns in words
 // LAST segment first (outer rings are the long ones: the persistent kernel lets the previous tile's result stores leave
 // beside the first segment it computes, and every kernel folds the layers in list order).  Returns in every lane the list
 // length.
+// k16: the first k16 words of the run are uint16 pairs, the rest uint8 quadruples (bits 9-14 of a chunk's second entry: how many
+// of ITS words are uint16; every word where the layer has no uint8 range).
 template <int CH>
-__device__ inline int emit_chunks(int nch, int col0, int words, int l, int2 *lst) {
+__device__ inline int emit_chunks(int nch, int col0, int words, int l, int2 *lst, int k16 = 1 << 20) {
     int suf = nch;                                   // inclusive suffix sum over the lanes
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -282,8 +284,10 @@ __device__ inline int emit_chunks(int nch, int col0, int words, int l, int2 *lst
         if (l + o < 64) suf += dn;
     }
     int2 *dst = lst + (suf - nch);
-    for (int c = 0; c < nch; ++c)
-        dst[c] = make_int2(col0 + c * CH, min(CH, words - c * CH) | ((c == nch - 1) ? 0x100 : 0) | (l << 16));
+    for (int c = 0; c < nch; ++c) {
+        const int valid = min(CH, words - c * CH), n16 = max(0, min(valid, k16 - c * CH));
+        dst[c] = make_int2(col0 + c * CH, valid | ((c == nch - 1) ? 0x100 : 0) | (n16 << 9) | (l << 16));
+    }
     return __shfl(suf, 0, 64);
 }
 
@@ -720,7 +724,10 @@ __device__ inline void wait_vm_young(int young) {
 // leaves in smeta[l] the suffix row to add and the side it belongs to (bit 30: the J side), or -1.
 template <int CH, bool PACK>
 __device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t RI, uint32_t RJ, int l, int2 *lst, int *smeta) {
-    int col0 = sd.bin_col0, words = active ? sd.bin_words : 0, sm = -1;
+    int col0 = sd.bin_col0, words = active ? sd.bin_words : 0, sm = -1, k16 = 1 << 20;
+    // (bit 31 of a side's maximum: one of its nodes holds a value >= 256 where the uint8 range has bytes)
+    const bool wide = ((RI | RJ) >> 31) != 0;
+    RI &= 0x7fffffffu; RJ &= 0x7fffffffu;
     if (active && sd.rank_col0 >= 0 && sd.suf_row0 >= 0) {
         const uint32_t Rm = min(RI, RJ);
         int wr = PACK ? (int)((Rm + 1) >> 1) : (int)Rm;
@@ -729,11 +736,22 @@ __device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t 
             col0 = sd.rank_col0;
             words = sd.rank_low + wr;
             sm = (sd.suf_row0 + wr) | (RI >= RJ ? 0 : (1 << 30));
+            if (PACK && sd.r8_col0 >= 0 && !wide) {
+                // uint8 range: the rank words beyond the first r8_r16 two-into-one.  The columns end with the uint16 range's
+                // (zeros beyond its cap), so the suffix row is capped there too.
+                const int over = wr - sd.r8_r16, wr8 = over > 0 ? (over + 1) >> 1 : 0, w8 = sd.r8_fixed + wr8;
+                if (wr8 <= sd.r8_cap && w8 >= 1 && w8 < words) {
+                    col0 = sd.r8_col0;
+                    words = w8;
+                    k16 = sd.r8_k16;
+                    sm = (sd.suf_row0 + min(sd.r8_r16 + 2 * wr8, sd.rank_cap)) | (RI >= RJ ? 0 : (1 << 30));
+                }
+            }
         }
     }
     if (l < 4) smeta[l] = sm;
     const int nch = (words + CH - 1) / CH;
-    return emit_chunks<CH>(nch, col0, words, l, lst);
+    return emit_chunks<CH>(nch, col0, words, l, lst, k16);
 }
 
 // TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
@@ -1156,18 +1174,19 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         const unsigned long long c_l0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
         for (int k = 0; k < n0; ++k) {
-            int cvalid, seg = 0;
+            int cvalid, seg = 0, n16 = 0;
             bool ends_seg = false;
             if constexpr (SEG) {
                 const int meta = __builtin_amdgcn_readfirstlane(clist[cur * a.list_cap + k].y);
                 cvalid = meta & 0xff;
                 ends_seg = (meta & 0x100) != 0;
+                n16 = (meta >> 9) & 0x3f;                 // leading words of uint16 pairs; the rest are uint8 quadruples
                 seg = meta >> 16;
             } else {
                 cvalid = min(CH, a.dcols_valid - k * CH);
             }
             work += (unsigned)cvalid;
-            if (a.dbg & 2) cvalid = 0;
+            if (a.dbg & 2) cvalid = n16 = 0;
             // chunk k has landed once everything older than the operations issued after its loads has retired
             // (the first chunk of a tile was waited for before the previous tile's stores went out)
             // (... and then the barrier at the top of the tile has already told every wave so: no second one)
@@ -1208,23 +1227,28 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     bv[buf][2 * qq + 1] = v.y;
                 }
             };
-            auto compute = [&](int buf) __attribute__((always_inline)) {
+            // BYTES: the words are four uint8 columns (the uint8 range of a packed layer) instead of two uint16 columns
+            auto compute = [&](int buf, auto BYTES) __attribute__((always_inline)) {
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
                     for (int cc = 0; cc < TC; ++cc) {
                         if constexpr (KIND == K_L1) ACC(r, cc) += fabs(av[buf][r] - bv[buf][cc]);
                         else if constexpr (KIND == K_SAD) part[r][cc] = __usad(av[buf][r], bv[buf][cc], part[r][cc]);
-                        else if constexpr (KIND == K_SAD16) part[r][cc] = __builtin_amdgcn_sad_u16(av[buf][r], bv[buf][cc], part[r][cc]);
-                        else if constexpr (KIND == K_ZP) part[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
+                        else if constexpr (KIND == K_SAD16) {
+                            if constexpr (decltype(BYTES)::value) part[r][cc] = __builtin_amdgcn_sad_u8(av[buf][r], bv[buf][cc], part[r][cc]);
+                            else part[r][cc] = __builtin_amdgcn_sad_u16(av[buf][r], bv[buf][cc], part[r][cc]);
+                        } else if constexpr (KIND == K_ZP) part[r][cc] += fabs(av[buf][r] - bv[buf][cc]);
                         else ACC(r, cc) = fma(av[buf][r], bv[buf][cc], ACC(r, cc));
                     }
             };
-            load_ops(0, 0);
-            int c = 0;
             constexpr int UNR = sizeof(T) == 4 ? 8 : HSD_F64_UNROLL;
+            // the words [c, cend) of the chunk
+            auto sweep = [&](int c, const int cend, auto BYTES) __attribute__((always_inline)) {
+            if (c >= cend) return;
+            load_ops(c, 0);
 #pragma unroll 1
-            for (; UNR > 2 && c + UNR <= cvalid; c += UNR) {        // straight-line body: counted LDS waits (see pair_kernel)
+            for (; UNR > 2 && c + UNR <= cend; c += UNR) {          // straight-line body: counted LDS waits (see pair_kernel)
                 if constexpr (DEFERS) {
                     // one group of the previous tile's results in front of every 8-word trip (~2 100 cycles of arithmetic apart:
                     // the store path never sees a burst; two bursts of 32 in front of the first two chunks: +0.25 of 16.7 ms)
@@ -1240,26 +1264,33 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     // tile lists lie there, inside the workgroup's LDS -- and the trip's eight words share one address register)
                     load_ops(c + u + 1, 1);
                     HSD_PIN_ORDER;
-                    compute(0);
+                    compute(0, BYTES);
                     HSD_PIN_ORDER;
                     load_ops(c + u + 2, 0);
                     HSD_PIN_ORDER;
-                    compute(1);
+                    compute(1, BYTES);
                     HSD_PIN_ORDER;
                 }
             }
 #pragma unroll 1
-            for (; c < cvalid; c += 2) {
+            for (; c < cend; c += 2) {
                 load_ops(c + 1, 1);
                 HSD_PIN_ORDER;
-                compute(0);
+                compute(0, BYTES);
                 HSD_PIN_ORDER;
-                if (c + 1 < cvalid) {
+                if (c + 1 < cend) {
                     load_ops(c + 2, 0);
                     HSD_PIN_ORDER;
-                    compute(1);
+                    compute(1, BYTES);
                     HSD_PIN_ORDER;
                 }
+            }
+            };
+            if constexpr (KIND == K_SAD16) {
+                sweep(0, n16, std::false_type{});
+                sweep(n16, cvalid, std::true_type{});
+            } else {
+                sweep(0, cvalid, std::false_type{});
             }
             if constexpr (SEG) {
                 if (ends_seg) {
@@ -1614,6 +1645,37 @@ __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_co
     // (rows beyond the node's own words stay 0: the matrix was cleared)
 }
 
+// uint8 range of a packed layer (HsdSegDesc::r8_*): what node i needs to stay uint16 in the layer's rank-form range
+//   need[(2 s) * npad + i]     = leading low-bin words up to and including the last one that holds a value >= 256
+//   need[(2 s + 1) * npad + i] = leading rank words that hold a value >= 256 (the ranks are descending)
+__global__ void u8_need_kernel(const uint32_t *__restrict__ X, int64_t npad, int64_t n, const HsdSegDesc d, uint32_t *__restrict__ need) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = 0;
+    if (i >= n || d.rank_col0 < 0) return;
+    const auto wide = [](uint32_t v) { return (v & 0xffffu) >= 256u || (v >> 16) >= 256u; };
+    uint32_t b8 = 0, r8 = 0;
+    for (int w = 0; w < d.rank_low; ++w)
+        if (wide(X[(int64_t)(d.rank_col0 + w) * npad + i])) b8 = (uint32_t)w + 1u;
+    for (int w = 0; w < d.rank_cap; ++w) {
+        if (!wide(X[(int64_t)(d.rank_col0 + d.rank_low + w) * npad + i])) break;
+        r8 = (uint32_t)w + 1u;
+    }
+    need[(int64_t)(2 * s) * npad + i] = b8;
+    need[(int64_t)(2 * s + 1) * npad + i] = r8;
+}
+
+// dst word w = the four uint16 values of source words 2 w, 2 w + 1 as saturated bytes (source words from n_src on count as
+// zero).  Saturated bytes are never compared: a tile with such a node does not read the uint8 range.
+__global__ void pack_u8_kernel(uint32_t *__restrict__ X, int64_t npad, int src_col, int n_src, int dst_col, int n_dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = blockIdx.y;
+    if (i >= npad || w >= n_dst) return;
+    const uint32_t a = 2 * w < n_src ? X[(int64_t)(src_col + 2 * w) * npad + i] : 0u;
+    const uint32_t b = 2 * w + 1 < n_src ? X[(int64_t)(src_col + 2 * w + 1) * npad + i] : 0u;
+    const auto sat = [](uint32_t v) { return v > 255u ? 255u : v; };
+    X[(int64_t)(dst_col + w) * npad + i] = sat(a & 0xffffu) | (sat(a >> 16) << 8) | (sat(b & 0xffffu) << 16) | (sat(b >> 16) << 24);
+}
+
 // above[(s * n_cand + q) * npad + i] = members of ring layer s of node i with bin index >= cand_bin[q]
 __global__ void count_above_kernel(PrepArgs p, const int *__restrict__ cand_bin, int n_cand, uint32_t *__restrict__ above) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1915,9 +1977,13 @@ __global__ void list_tile_max_kernel(const int32_t *__restrict__ gl, int ntiles,
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (int64_t)ntiles * n_seg) return;
     const int s = (int)(k / ntiles), t = (int)(k % ntiles);
-    uint32_t m = 0;
-    for (int e = 0; e < 8; ++e) m = max(m, rmax16[(int64_t)s * ngran16 + gl[(int64_t)8 * t + e]]);
-    tmax[k] = m;
+    uint32_t m = 0, wide = 0;                        // bit 31: the granule holds a node too wide for the layer's uint8 range
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t v = rmax16[(int64_t)s * ngran16 + gl[(int64_t)8 * t + e]];
+        m = max(m, v & 0x7fffffffu);
+        wide |= v & 0x80000000u;
+    }
+    tmax[k] = m | wide;
 }
 
 // tau16[i] = tau[i] rounded UP to bfloat16 (tau >= 0), i in [lo, hi)
@@ -2595,6 +2661,9 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         ctx->gran_order.clear();
         if (best_sorted) ctx->gran_order = best_order;
         int suf_rows = 1;                                         // row 0: zeros
+        const char *e8 = getenv("HSD_U8");
+        const bool u8_ok = !(e8 && atoi(e8) == 0);               // HSD_U8=0: no uint8 ranges (tests: same bits either way)
+        std::vector<int> r8_reserved((size_t)nl_hist, -1);
         for (int sgi = 0; sgi < nl_hist; ++sgi) {
             const LayerPlan &bp = best_plan[(size_t)sgi];
             if (bp.q < 0) continue;
@@ -2610,6 +2679,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             for (int g = 0; g < ngran; ++g)                        // the one-tile kernel plans from 64-node granules in natural order
                 rmax_sel[(size_t)sgi * ngran + g] = std::max(std::max(gm[4 * g], gm[4 * g + 1]), std::max(gm[4 * g + 2], gm[4 * g + 3]));
             col += (int)round_up(low_w + bp.cap, CH);
+            if (pack && u8_ok) { r8_reserved[(size_t)sgi] = col; col += (int)round_up(low_w + bp.cap + 1, CH); }
         }
         if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax16, (size_t)nl_hist * ngran16))) return rc;
         ctx->ngran16 = ngran16;
@@ -2674,6 +2744,92 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
             else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
+        }
+        // ---- uint8 ranges (persistent kernel).  Most values of a rank-form range are small: ring 2 of a scale-free graph has a
+        // handful of hubs in front of hundreds of ordinary members, and its tail counts fall below 256 a few bins up.  v_sad_u8
+        // takes four such columns per instruction where v_sad_u16 takes two.  Per layer: keep the first b8 low-bin words and the
+        // first r16 rank words as they are and store the rest two-words-into-one as bytes; a tile may read that range when none
+        // of its nodes holds a value >= 256 in the byte part (flag in bit 31 of its granules' maxima).  (b8, r16) by expected
+        // words over all tile pairs in the chosen order, exact from the sorted tile maxima of the tiles that qualify.
+        for (int sgi = 0; sgi < nl_hist && pack && u8_ok; ++sgi) {
+            if (tab[sgi].rank_col0 < 0 || r8_reserved[(size_t)sgi] < 0 || G16 < 8) continue;
+            const int low = tab[sgi].rank_low, cap = tab[sgi].rank_cap;
+            DevTmp dneed, dgn;
+            HSD_TMP_ALLOC(ctx, dneed, (size_t)2 * npad * sizeof(uint32_t));
+            HSD_TMP_ALLOC(ctx, dgn, (size_t)2 * ngran16 * sizeof(uint32_t));
+            HSD_HIP(ctx, hipMemsetAsync(dneed.p, 0, (size_t)2 * npad * sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(u8_need_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, tab[sgi],
+                               dneed.as<uint32_t>());
+            hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), 2u), dim3(256), 0, ctx->stream, dneed.as<uint32_t>(), npad, ngran16,
+                               dgn.as<uint32_t>());
+            std::vector<uint32_t> gneed((size_t)2 * ngran16);
+            HSD_HIP(ctx, hipMemcpyAsync(gneed.data(), dgn.p, gneed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t *gb8 = gneed.data(), *gr8 = gneed.data() + ngran16;
+            uint32_t *gR = rmax16_sel.data() + (size_t)sgi * ngran16;
+            const int64_t nt = (G16 + 7) / 8;
+            std::vector<uint32_t> tb8((size_t)nt, 0u), tr8((size_t)nt, 0u), tR((size_t)nt, 0u);
+            for (int64_t t = 0; t < nt; ++t)
+                for (int64_t e = 8 * t; e < std::min<int64_t>(G16, 8 * t + 8); ++e) {
+                    const int64_t g = ctx->gran_order.empty() ? e : ctx->gran_order[(size_t)e];
+                    tb8[(size_t)t] = std::max(tb8[(size_t)t], gb8[g]);
+                    tr8[(size_t)t] = std::max(tr8[(size_t)t], gr8[g]);
+                    tR[(size_t)t] = std::max(tR[(size_t)t], gR[g]);
+                }
+            std::vector<int> cb, cr;
+            for (int v : {0, 2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 64}) if (v < low) cb.push_back(v);
+            cb.push_back(low);
+            for (int v : {0, 1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 48}) if (v < cap) cr.push_back(v);
+            cr.push_back(cap);
+            double best_save = 0.0;
+            int best_b = -1, best_r = -1;
+            std::vector<int64_t> wrs;
+            for (int b8 : cb)
+                for (int r16 : cr) {
+                    const int fixed = b8 + r16 + (low - b8 + 1) / 2;
+                    wrs.clear();
+                    for (int64_t t = 0; t < nt; ++t)
+                        if ((int)tb8[(size_t)t] <= b8 && (int)tr8[(size_t)t] <= r16) wrs.push_back(words_of(tR[(size_t)t]));
+                    std::sort(wrs.begin(), wrs.end());
+                    long double save = 0.0L;
+                    const int64_t m = (int64_t)wrs.size();
+                    for (int64_t k2 = 0; k2 < m; ++k2) {
+                        int64_t wr = wrs[(size_t)k2];
+                        if (low + wr == 0) wr = 1;
+                        if (wr > cap) break;
+                        const int64_t c16 = low + wr, c8 = fixed + std::max<int64_t>(wr - r16, 0) / 2 + (std::max<int64_t>(wr - r16, 0) & 1);
+                        if (c8 >= 1 && c8 < c16) save += (long double)(c16 - c8) * (long double)(m - k2);
+                    }
+                    const double sv = (double)(save / ((long double)nt * (nt + 1) / 2));
+                    if (sv > best_save) { best_save = sv; best_b = b8; best_r = r16; }
+                }
+            if (best_b < 0 || best_save < 0.5) continue;
+            HsdSegDesc &d = tab[sgi];
+            d.r8_col0 = r8_reserved[(size_t)sgi];
+            d.r8_k16 = best_b + best_r;
+            d.r8_fixed = d.r8_k16 + (low - best_b + 1) / 2;
+            d.r8_r16 = best_r;
+            d.r8_cap = (cap - best_r + 1) / 2;
+            uint32_t *X = (uint32_t *)ctx->d_X;
+            if (best_b > 0)
+                HSD_HIP(ctx, hipMemcpyAsync(X + (size_t)d.r8_col0 * npad, X + (size_t)d.rank_col0 * npad, (size_t)best_b * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            if (best_r > 0)
+                HSD_HIP(ctx, hipMemcpyAsync(X + (size_t)(d.r8_col0 + best_b) * npad, X + (size_t)(d.rank_col0 + low) * npad, (size_t)best_r * npad * sizeof(uint32_t),
+                                            hipMemcpyDeviceToDevice, ctx->stream));
+            const int nb8 = (low - best_b + 1) / 2;
+            if (nb8 > 0)
+                hipLaunchKernelGGL(pack_u8_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)nb8), dim3(256), 0, ctx->stream, X, npad, d.rank_col0 + best_b,
+                                   low - best_b, d.r8_col0 + d.r8_k16, nb8);
+            if (d.r8_cap > 0)
+                hipLaunchKernelGGL(pack_u8_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)d.r8_cap), dim3(256), 0, ctx->stream, X, npad,
+                                   d.rank_col0 + low + best_r, cap - best_r, d.r8_col0 + d.r8_fixed, d.r8_cap);
+            for (int g = 0; g < ngran16; ++g)
+                if ((int)gb8[g] > best_b || (int)gr8[g] > best_r) gR[g] |= 0x80000000u;
+            HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax16 + (size_t)sgi * ngran16, gR, (size_t)ngran16 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // gR (rmax16_sel) / temporaries
+            if (getenv("HSD_PLAN_VERBOSE"))
+                fprintf(stderr, "[hsd plan] layer %d uint8 range: %d low-bin + %d rank words stay uint16, %d + up to %d words of bytes; saves %.1f words per tile pair\n", sgi,
+                        best_b, best_r, nb8, d.r8_cap, best_save);
         }
     }
     if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {

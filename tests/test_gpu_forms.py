@@ -160,6 +160,35 @@ def test_persistent_kernels_bit_identical(engine, nw):
         assert work > 0
 
 
+def test_uint8_ranges_bit_identical(engine, capfd):
+    """Packed layers keep a third range with their small values as bytes (v_sad_u8: four columns per instruction); tiles
+    whose granules hold a node with a value >= 256 there must not read it, and must still see their own largest ring.  A
+    scale-free graph large enough for hubs (ring 2 in the thousands beside rings of a few dozen): the persistent kernel with
+    the ranges (the plan must have built one), without them (HSD_U8=0) and the one-tile kernel agree bit for bit -- matrix,
+    row block off the tile grid, natural and sorted granule order."""
+    g = _scale_free(16000 + 77, seed=11)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    with _Env(HSD_STREAM=0, HSD_U8=0):
+        engine.pair_prepare(0, 1, 0, 2)
+        ref = engine.pair_rows_host(0, 3000)
+        ref2 = engine.pair_rows_host(9000 + 4, 9000 + 1300)
+    for sort in ("1", "0"):
+        words = {}
+        for u8 in ("1", "0"):
+            with _Env(HSD_STREAM=1, HSD_U8=u8, HSD_GRAN_SORT=sort, HSD_PLAN_VERBOSE=1):
+                capfd.readouterr()
+                engine.pair_prepare(0, 1, 0, 2)
+                plan = capfd.readouterr().err
+                got = engine.pair_rows_host(0, 3000)
+                words[u8] = engine.pair_work()
+                got2 = engine.pair_rows_host(9000 + 4, 9000 + 1300)
+            assert ("uint8 range" in plan) == (u8 == "1"), plan
+            assert np.array_equal(got, ref), (sort, u8, np.abs(got - ref).max())
+            assert np.array_equal(got2, ref2), (sort, u8)
+        assert words["1"] < words["0"], words            # (rows 0..3000 of a preferential-attachment graph are its hubs: few tiles qualify)
+
+
 def test_persistent_kernel_corner_shapes(engine):
     """Forced persistent kernel on shapes its size heuristic would not pick: a distance with NO histogram layer (K = 1,
     layers 0..0: tiles without operand chunks, only the ring-0 term), and a hierarchy too deep for its LDS budget
