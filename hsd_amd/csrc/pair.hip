@@ -1272,6 +1272,14 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     HSD_PIN_ORDER;
                 }
             }
+            if constexpr (DEFERS) {
+                // ... and one in front of the shorter rest of a sweep (four words or more)
+                if (c + 4 <= cend && pend_g < 8) {
+                    if (pend_g == 4 && pend_mirror) transpose_acc();
+                    vm_seq += store_group(pend_g, pend_ms, pend_mirror);
+                    ++pend_g;
+                }
+            }
 #pragma unroll 1
             for (; c < cend; c += 2) {
                 load_ops(c + 1, 1);
