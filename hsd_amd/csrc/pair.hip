@@ -31,6 +31,9 @@ namespace {
 #ifndef HSD_PIN
 #define HSD_PIN 1
 #endif
+#ifndef HSD_STORE_BITS
+#define HSD_STORE_BITS "nt"     // cache-policy bits of the persistent kernel's result stores (measured: see DESIGN.md section 5)
+#endif
 #ifndef HSD_ABLATE
 #define HSD_ABLATE 0            // measurement builds only: bit 0: the mirrored half without the accumulator exchange (wrong results)
 #endif
@@ -199,7 +202,7 @@ __device__ inline void glds16_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_
 // eight stores that share a base.  csrc/check_m0.py verifies both pads in the disassembly.
 template <bool NT>
 __device__ inline void gstore16_s(uint64_t sbase, uint32_t lane_off, v2f64 val) {
-    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 " HSD_STORE_BITS "\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(val), "s"(sbase) : "memory");
 }
 
@@ -1087,6 +1090,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         };
 #if HSD_STAMPS
         if (nt) put(std::true_type{}); else put(std::false_type{});       // HSD_DEBUG bit 2: plain instead of non-temporal stores
+#elif defined(HSD_PLAIN_STORES)
+        put(std::false_type{});                                           // measurement build
 #else
         put(std::true_type{});
 #endif
