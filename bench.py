@@ -290,6 +290,26 @@ def traffic_fields(key):
     return t, None
 
 
+def fill_reference(eng, mat, kernel_ms):
+    """What this GPU's memory system takes for the output alone: hipMemsetAsync over the same row block (80 GB at N = 100k), timed
+    the same way right after the kernel.  `peak` stays the 8 TB/s of MI355X_MICROARCH.md; this is the measured ceiling of a pure
+    write stream of that size beside it (5.9-6.0 TB/s for 80 GB, 6.6 TB/s for 800 MB)."""
+    import ctypes as C
+    nbytes = mat.rows * mat.ld * 8
+    try:
+        eng._call("hsd_memset", C.c_void_p(mat.ptr), 0, C.c_size_t(nbytes))
+        eng.sync()
+        reps = 3
+        eng.timer_start()
+        for _ in range(reps):
+            eng._call("hsd_memset", C.c_void_p(mat.ptr), 0, C.c_size_t(nbytes))
+        ms = eng.timer_stop() / reps
+    except Exception as e:          # noqa: BLE001  (a reference figure: never fails the bench line)
+        return dict(error=str(e)[:80])
+    return dict(call="hipMemsetAsync over the output block", bytes=nbytes, ms=round(ms, 4), GBps=round(nbytes / ms / 1e6, 1),
+                kernel_over_fill=round(kernel_ms / ms, 3) if ms > 0 else None)
+
+
 def kernel_roofline(n, rows, res, steps, metric, traffic_key=None):
     """bytes_alg = 8 * rows * N (each fp64 output written once) + operand matrix read once; beside it
     the vector instructions the launch needs at minimum (fp64 W1: 2 per column pair, integer SAD: 1 per word pair,
@@ -453,6 +473,8 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
         res["matrix_check"] = {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")}
         if rk.world == 1 and metric == "wasserstein":
             res["fused_knn"] = fused_knn(eng, mat, n, 20)
+        # (last: it clears the block the checks above read)
+        res["roofline"]["fill_same_bytes"] = fill_reference(eng, mat, res["roofline"]["kernel_ms"])
         mat.free()
         out[variant] = res
     return dict(variants=out, sweep=sweep, n_bins=n_bins, rows=(r0, r1),

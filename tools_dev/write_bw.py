@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sustained HBM write bandwidth reference: hipMemsetAsync of an 800 MB / 8 GB buffer, back to back."""
+"""Sustained HBM write bandwidth reference: hipMemsetAsync of an 800 MB / 8 GB / 80 GB buffer, back to back."""
 import ctypes as C
 import os
 import sys
@@ -8,12 +8,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsd_amd                                                  # noqa: E402
 
 eng = hsd_amd.Engine(0)
-for nbytes in (800_000_000, 8_000_000_000):
+for nbytes in (800_000_000, 8_000_000_000, 80_000_000_000):
     p = eng.malloc(nbytes)
     for _ in range(3):
         eng._call("hsd_memset", C.c_void_p(p), 0, C.c_size_t(nbytes))
     eng.sync()
-    reps = 20
+    reps = 20 if nbytes < 10**10 else 5
     eng.timer_start()
     for _ in range(reps):
         eng._call("hsd_memset", C.c_void_p(p), 0, C.c_size_t(nbytes))
