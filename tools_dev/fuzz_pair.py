@@ -1,14 +1,15 @@
 """dev: randomized soak of the pair kernels: row blocks at arbitrary offsets, persistent / one-tile kernels, tile edges,
 forms of the zero-pad layers, tile composition (sorted / natural granule order) -- every combination must reproduce the
 rows of a reference matrix (one-tile kernel, bin form), bit for bit for the Wasserstein distances.
-usage: python3 tools_dev/fuzz_pair.py [seconds=120] [seed=1]      (tests/test_gpu_fuzz.py runs one seed inside -m gpu)"""
+usage: python3 tools_dev/fuzz_pair.py [seconds=120] [seed=1] [n_max=4200]      (tests/test_gpu_fuzz.py runs one seed inside -m gpu;
+n_max ~12000 brings hubs whose rings exceed a byte: tiles that must not read a layer's uint8 range)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsd_amd
 from hsd_amd.graph import barabasi_albert, erdos_renyi, connect_components
 
-HOOKS = ("HSD_STREAM", "HSD_TILE", "HSD_RANK", "HSD_SAD16", "HSD_XCD_DEAL", "HSD_SUPERTILE", "HSD_GRAN_SORT")
+HOOKS = ("HSD_STREAM", "HSD_TILE", "HSD_RANK", "HSD_SAD16", "HSD_XCD_DEAL", "HSD_SUPERTILE", "HSD_GRAN_SORT", "HSD_U8")
 
 
 def with_env(env, fn):
@@ -49,6 +50,7 @@ def soak(eng, seed=1, budget_s=120.0, max_blocks=None, n_max=4200):
             if rng.random() < 0.2: env["HSD_XCD_DEAL"] = "0"
             if rng.random() < 0.2: env["HSD_SUPERTILE"] = str(int(rng.choice([1, 4, 16])))
             if rng.random() < 0.3: env["HSD_GRAN_SORT"] = "0"
+            if rng.random() < 0.2: env["HSD_U8"] = "0"
             gran = int(rng.choice([1, 2, 4, 16, 64, 128]))
             r0 = int(rng.integers(0, n)) // gran * gran
             r1 = int(rng.integers(r0 + 1, n + 1)) if rng.random() < 0.7 else n
@@ -75,7 +77,7 @@ def soak(eng, seed=1, budget_s=120.0, max_blocks=None, n_max=4200):
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     t0 = time.time()
-    cases, bad = soak(hsd_amd.Engine(0), int(sys.argv[2]) if len(sys.argv) > 2 else 1, budget)
+    cases, bad = soak(hsd_amd.Engine(0), int(sys.argv[2]) if len(sys.argv) > 2 else 1, budget, n_max=int(sys.argv[3]) if len(sys.argv) > 3 else 4200)
     if bad:
         print("MISMATCH", bad, flush=True)
         sys.exit(1)

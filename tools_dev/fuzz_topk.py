@@ -37,6 +37,7 @@ def soak(eng, seed=1, budget_s=90.0, max_calls=None, n_max=5000):
             if rng.random() < 0.6: env["HSD_STREAM"] = "1"
             if rng.random() < 0.2: env["HSD_TOPK_CAP"] = str(k + int(rng.integers(1, 40)))
             if rng.random() < 0.3: env["HSD_GRAN_SORT"] = "0"
+            if rng.random() < 0.2: env["HSD_U8"] = "0"          # (read at prepare time: the next graph's)
             a = int(rng.integers(0, n - 1)) // 4 * 4 if rng.random() < 0.5 else 0
             b = int(rng.integers(a + 1, n + 1)) if a else n
             os.environ.update(env)
@@ -62,7 +63,7 @@ def soak(eng, seed=1, budget_s=90.0, max_calls=None, n_max=5000):
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
     t0 = time.time()
-    cases, bad = soak(hsd_amd.Engine(0), int(sys.argv[2]) if len(sys.argv) > 2 else 1, budget)
+    cases, bad = soak(hsd_amd.Engine(0), int(sys.argv[2]) if len(sys.argv) > 2 else 1, budget, n_max=int(sys.argv[3]) if len(sys.argv) > 3 else 5000)
     if bad:
         print("MISMATCH", bad, flush=True)
         sys.exit(1)
