@@ -1446,26 +1446,6 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
           if (!first_landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           wg_barrier();
           if (!((a.dbg & 1) && ACC(0, 0) != -1.0)) {      // HSD_DEBUG bit 0 (measurement): the sweep without its epilogue
-            // Most tiles of a sweep's later phases hold no candidate at all: one comparison per value against the largest
-            // threshold of its row granule (and, mirrored, of its column granule) -- sixteen scalars that came with the tile's
-            // plan -- and a vote decide whether the per-row thresholds are fetched at all (they are global loads: a tile's worth
-            // of latency).  Per 16-node granule, not per tile: a single hub among a tile's 256 nodes has a threshold ten times
-            // its neighbours'.
-            {
-                const double *tg = reinterpret_cast<const double *>(meta + ms * META + 24);
-                double ti4[4], tj4[4];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    ti4[qq] = tg[4 * (w >> 1) + qq];
-                    tj4[qq] = mirror ? tg[8 + 4 * (w & 1) + qq] : -INFINITY;
-                }
-                bool any = false;
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < TC; ++cc) any |= ACC(r, cc) <= fmax(ti4[r >> 1], tj4[cc >> 1]);
-                if (__ballot(any) == 0ull) goto epilogue_done;
-            }
             // this tile's granules: the node ids of its rows / columns
             int GI[4], GJ[4];
 #pragma unroll
@@ -1476,31 +1456,61 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             // keep (j, v) for row i when v <= tau[i]; on a symmetric region the pair also serves row j (a tile on the
             // diagonal holds both orientations of its pairs: row i only, and not i itself).  The thresholds are this launch's
             // (the host tightens them between the phases of a sweep), rounded up to bfloat16, staged with the tile.
+            // A tile holds ~6 such pairs among its 16 384 (BA N = 100k, k = 20), so the test that runs for every value must be
+            // cheap: distances are non-negative, so the HIGH words of two doubles order like the doubles, and a bfloat16 threshold
+            // has an empty low word -- v <= tau implies hi(v) <= hi(tau).  Per lane the smallest high word of each of its 8 rows
+            // and 8 columns (112 v_min_i32) against the row's / column's threshold; only a row or column that passes (rare:
+            // the branch is skipped when no lane of the wave does) tests its eight values exactly.  (Before: two fp64 compares
+            // and two divergent branches per value behind a per-granule vote: 0.45 ms of every 1.8-ms phase.)
             auto bf = [](uint16_t h) __attribute__((always_inline)) -> double { return (double)__uint_as_float((uint32_t)h << 16); };
-            double tj_[TC];
+            // (SIGNED high words: a symmetric-KL value that rounding left at -1e-17 is below every threshold, as it should be)
+            auto hi32 = [](double v) __attribute__((always_inline)) -> int { return (int)(__double_as_longlong(v) >> 32); };
+            int cmin[TC];
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) tj_[cc] = mirror ? bf(tau16b[128 + wj + 16 * (cc >> 1) + (cc & 1)]) : -1.0;
+            for (int cc = 0; cc < TC; ++cc) cmin[cc] = 0x7fffffff;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const int64_t i = (int64_t)16 * GI[r >> 1] + 2 * ly + (r & 1);
-                const double ti_ = bf(tau16b[wi + 16 * (r >> 1) + (r & 1)]);
+                int rmin = 0x7fffffff;
 #pragma unroll
                 for (int cc = 0; cc < TC; ++cc) {
-                    const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
-                    const double v = ACC(r, cc);
-                    if (v <= ti_ && i != j) {
-                        const int slot = atomicAdd(a.cand_cnt + i, 1);
-                        if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
+                    const int h = hi32(ACC(r, cc));
+                    rmin = min(rmin, h);
+                    cmin[cc] = min(cmin[cc], h);
+                }
+                const double ti_ = bf(tau16b[wi + 16 * (r >> 1) + (r & 1)]);
+                if (rmin <= hi32(ti_)) {
+                    const int64_t i = (int64_t)16 * GI[r >> 1] + 2 * ly + (r & 1);
+#pragma unroll
+                    for (int cc = 0; cc < TC; ++cc) {
+                        const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
+                        const double v = ACC(r, cc);
+                        if (v <= ti_ && i != j) {
+                            const int slot = atomicAdd(a.cand_cnt + i, 1);
+                            if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
+                        }
                     }
-                    if (v <= tj_[cc]) {
-                        const int slot = atomicAdd(a.cand_cnt + j, 1);
-                        if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
+                }
+            }
+            if (mirror) {
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) {
+                    const double tj_ = bf(tau16b[128 + wj + 16 * (cc >> 1) + (cc & 1)]);
+                    if (cmin[cc] <= hi32(tj_)) {
+                        const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
+#pragma unroll
+                        for (int r = 0; r < TR; ++r) {
+                            const int64_t i = (int64_t)16 * GI[r >> 1] + 2 * ly + (r & 1);
+                            const double v = ACC(r, cc);
+                            if (v <= tj_) {
+                                const int slot = atomicAdd(a.cand_cnt + j, 1);
+                                if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
+                            }
+                        }
                     }
                 }
             }
             // (vm_seq stays as it is: it must remain a LOWER bound of the operations issued, and these are data dependent)
           }
-          epilogue_done:;
         } else if ((a.dbg & 1) && ACC(0, 0) != -1.0) {
             // ablation: no stores
         } else if (DEFERS && has1) {
