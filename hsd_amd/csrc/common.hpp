@@ -110,7 +110,7 @@ struct hsd_ctx {
     std::vector<int32_t> gran_order;   // granules of the nodes [0, n - n % 128) in tile order (empty: natural order)
     uint32_t *d_suf = nullptr;         // suffix sums of the rank columns [suf_rows][npad] (row 0: zeros)
     int suf_rows = 0;
-    struct GranList { int64_t begin, end; int32_t *d_gl; uint32_t *d_tmax; int ntiles; double *d_ttau; };   // d_ttau: k-nearest sweep, per list granule
+    struct GranList { int64_t begin, end; int32_t *d_gl; uint32_t *d_tmax; int ntiles; };
     std::vector<GranList> gran_lists;
     int list_cap = 0;                  // entries of the pair kernel's per-tile chunk list (LDS)
     int *d_tile_ctr = nullptr;         // persistent pair kernel: 4 sets of 8 per-XCD tile counters

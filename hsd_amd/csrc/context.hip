@@ -71,7 +71,7 @@ void hsd_release_operands(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_rmax);
     hsd_dev_free(ctx->d_rmax16);
     hsd_dev_free(ctx->d_suf);
-    for (auto &g : ctx->gran_lists) { (void)hipFree(g.d_gl); (void)hipFree(g.d_tmax); (void)hipFree(g.d_ttau); }
+    for (auto &g : ctx->gran_lists) { (void)hipFree(g.d_gl); (void)hipFree(g.d_tmax); }
     ctx->gran_lists.clear();
     ctx->gran_order.clear();
     ctx->suf_rows = 0;

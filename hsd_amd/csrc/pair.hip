@@ -83,6 +83,7 @@ struct PairArgs {
     int *tile_ctr;          // persistent kernel: [8] tiles drawn so far from each XCD's run (zeroed before the launch)
     int ctr_slot;           // which of the context's counter sets this region uses (regions of a row block run side by side)
     int phase, n_phases;    // host side: this launch covers the tile groups of phase `phase` of `n_phases` (0 / 0: all of them)
+    int phase_w;            // ... of the phases [phase, phase + phase_w) (0 counts as 1): a sweep's later launches cover several
     int dbg;                // HSD_DEBUG ablation bits: 1 = no stores, 2 = no arithmetic
     // fused k-nearest consumer (hsd_pair_topk): instead of storing the tile, every value below its
     // row's threshold tau is appended to that row's candidate list
@@ -91,7 +92,6 @@ struct PairArgs {
     const uint32_t *tmax_i, *tmax_j;   // [n_seg][ntl]: most members above the segment's threshold among a list tile's nodes
     int ntl_i, ntl_j;               // list tiles per side (row stride of tmax)
     const uint32_t *suf;            // suffix sums of the rank columns [rows][npad] (HsdSegDesc::suf_row0)
-    const double *ttau_i, *ttau_j;  // k-nearest sweep: per list granule (8 per tile), the largest threshold among its 16 rows (this launch's tau)
     const uint16_t *tau16;          // k-nearest sweep: this launch's thresholds as bfloat16 rounded UP, indexed like tau (persistent kernel)
     unsigned long long *stamps;     // HSD_DEBUG bit 3: per-workgroup lifetimes (measurement), else nullptr
     const double *tau;      // [n] per-node threshold, or nullptr for the normal matrix output
@@ -773,11 +773,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     T *sbase = reinterpret_cast<T *>(lds_raw);
     int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
     int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths; [2]: the tile index drawn for the tile after next
-    // [3][56] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side), per layer segment
-    // the most members above its threshold on the I side (16-19) and on the J side (20-23), and (k-nearest sweep) the
-    // largest threshold within each of the tile's 8 row granules / 8 column granules as doubles (24-39, 40-55)
+    // [3][24] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side), per layer segment
+    // the most members above its threshold on the I side (16-19) and on the J side (20-23; bit 31: see plan_segment_min)
     int *meta = nlist + 4;
-    constexpr int META = 56;
+    constexpr int META = 24;
     int *smeta = meta + 3 * META;                    // [2][4]: per layer segment, suffix row | side << 30, or -1
     SegDesc *segd = reinterpret_cast<SegDesc *>(smeta + 8);      // [4]
     // auxiliary per-node vectors of the current and the next tile: [2 tiles][n_aux][I: 128 doubles | J: 128 doubles]
@@ -931,10 +930,6 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     if (l >= 16 && l < 20 && l - 16 < a.n_seg) p = reinterpret_cast<const int *>(a.tmax_i) + (int64_t)(l - 16) * a.ntl_i + mti;
                     if (l >= 20 && l < 24 && l - 20 < a.n_seg) p = reinterpret_cast<const int *>(a.tmax_j) + (int64_t)(l - 20) * a.ntl_j + mtj;
                 }
-            }
-            if constexpr (TOPK) {
-                if (l >= 24 && l < 40) p = reinterpret_cast<const int *>(a.ttau_i) + 16 * (int64_t)mti + (l - 24);
-                if (l >= 40 && l < 56) p = reinterpret_cast<const int *>(a.ttau_j) + 16 * (int64_t)mtj + (l - 40);
             }
             v = *p;
         }
@@ -1836,18 +1831,20 @@ int tile_edge(const hsd_ctx *ctx) {
 // nullptr (formula order in the kernel) when disabled or on allocation failure.
 // cls: 0 = every tile; 1 = interior tiles only (off the diagonal of a symmetric region, not in a partial last row /
 // column: the persistent kernel's share); 2 = the others (stored with per-element masks by the one-tile kernel).
-// phase / n_phases: only the groups whose (group row + group column) % n_phases == phase -- an anti-diagonal sample of the
-// pair space in which every block of rows meets 1 / n_phases of the column blocks (the k-nearest consumer tightens its
-// thresholds between such phases).
+// phase / n_phases / phase_w: only the groups whose (group row + group column) % n_phases lies in [phase, phase + phase_w) -- an
+// anti-diagonal sample of the pair space in which every block of rows meets phase_w / n_phases of the column blocks (the
+// k-nearest consumer tightens its thresholds between such phases).
 const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls, bool part_i, bool part_j, int *count, int phase = 0,
-                       int n_phases = 1) {
+                       int n_phases = 1, int phase_w = 1) {
     const char *e = getenv("HSD_SUPERTILE");
     const int S = e ? atoi(e) : 8;
     if (S <= 1 && cls == 0 && n_phases <= 1) { if (count) *count = -1; return nullptr; }
     const char *ed = getenv("HSD_XCD_DEAL");
     const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
     if (n_phases < 1) n_phases = 1;
-    const int key = std::max(S, 1) + (phase << 8) + (n_phases << 12) + (deal << 16) + (cls << 20) + ((int)part_i << 24) + ((int)part_j << 25);
+    if (phase_w < 1) phase_w = 1;
+    // (S < 256, phase < 32, n_phases <= 32, phase_w <= 32)
+    const int key = (std::max(S, 1) & 0xff) + (phase << 8) + (n_phases << 13) + (phase_w << 19) + (deal << 25) + (cls << 26) + ((int)part_i << 28) + ((int)part_j << 29);
     for (size_t k = 0; k < ctx->tile_lists.size(); ++k) {
         const auto &c = ctx->tile_lists[k];
         if (c.tiles_i == tiles_i && c.tiles_j == tiles_j && c.sym == sym && c.group == key) {
@@ -1866,7 +1863,7 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
     std::vector<size_t> group_begin;
     for (int sr = 0; sr < tiles_i; sr += G)
         for (int sc = sym ? sr : 0; sc < tiles_j; sc += G) {
-            if ((sr / G + sc / G) % n_phases != phase) continue;
+            { const int res = (sr / G + sc / G) % n_phases; if (res < phase || res >= phase + phase_w) continue; }
             group_begin.push_back(order.size());
             for (int ti = sr; ti < std::min(sr + G, tiles_i); ++ti)
                 for (int tj = std::max(sc, sym ? ti : 0); tj < std::min(sc + G, tiles_j); ++tj) {
@@ -1906,8 +1903,12 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     constexpr int CH = stream_chunk_cols(KIND);
     constexpr int BT = 128;
     // stages, chunk lists + lengths, granule ids + suffix rows of two tiles, per-node vectors, suffix sums
-    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 56 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
+    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 24 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
                        (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t) + (TOPK ? 512 : 0);
+    // (two workgroups per CU need 2 x lds <= 160 KiB: the integer kinds with three per-node vectors sit ~300 bytes below that -- at 96
+    // bytes above it, after the segment descriptions had grown, the k-nearest sweep of BA N = 200k ran at half occupancy: 105 vs 66 ms)
+    if (getenv("HSD_PLAN_VERBOSE") && 2 * lds > (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor)
+        fprintf(stderr, "[hsd stream<%d,%d,%d>] %zu bytes of LDS per workgroup: ONE workgroup per CU\n", KIND, NW, (int)TOPK, lds);
     // the attribute is per device: remembered per context (one context per GPU), not per process
     size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
     if (lds > attr_lds) {
@@ -2021,18 +2022,6 @@ __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, i
     tau16[i] = (uint16_t)b;
 }
 
-// ttau[g] = largest threshold among the 16 nodes of list granule g (eight per list tile; tau is indexed by node; nodes outside
-// [lo, hi) have none)
-__global__ void list_granule_tau_kernel(const int32_t *__restrict__ gl, int ngran, const double *__restrict__ tau, int64_t lo, int64_t hi,
-                                        double *__restrict__ ttau) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngran) return;
-    const int64_t node0 = (int64_t)16 * gl[g];
-    double v = -INFINITY;
-    for (int e = 0; e < 16; ++e)
-        if (node0 + e >= lo && node0 + e < hi) v = fmax(v, tau[node0 + e]);
-    ttau[g] = v;
-}
 
 // The granule list of the node range [begin, end) (begin on a granule, a whole number of 128-node tiles): its granules in
 // the order hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank
@@ -2049,7 +2038,7 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
     if (sorted) { for (int32_t g : ctx->gran_order) if (g >= g0 && g < g1) gl.push_back(g); }
     else for (int64_t g = g0; g < g1; ++g) gl.push_back((int32_t)g);
     if ((int64_t)gl.size() != g1 - g0 || gl.size() % 8 != 0 || gl.empty()) return false;
-    hsd_ctx::GranList L{begin, key_end, nullptr, nullptr, (int)(gl.size() / 8), nullptr};
+    hsd_ctx::GranList L{begin, key_end, nullptr, nullptr, (int)(gl.size() / 8)};
     if (hipMalloc(reinterpret_cast<void **>(&L.d_gl), gl.size() * sizeof(int32_t)) != hipSuccess) return false;
     if (hipMemcpy(L.d_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(L.d_gl); return false; }
     if (ctx->d_rmax16 && ctx->n_seg > 0) {
@@ -2059,11 +2048,6 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
         // every hsd_pair_* call joins its streams before it returns)
         hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, L.d_gl, L.ntiles, ctx->d_rmax16,
                            ctx->ngran16, ctx->n_seg, L.d_tmax);
-    }
-    if (hipMalloc(reinterpret_cast<void **>(&L.d_ttau), (size_t)L.ntiles * 8 * sizeof(double)) != hipSuccess) {
-        (void)hipFree(L.d_gl);
-        if (L.d_tmax) (void)hipFree(L.d_tmax);
-        return false;
     }
     ctx->gran_lists.push_back(L);
     *out = L;
@@ -2098,8 +2082,8 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
             // kernel's masks (natural composition: the KL kinds have no sorted order).
             const bool diag_masked = a.sym && !wass;
             int n_in = -1, n_mask = 0;
-            const int2 *l_in = tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, diag_masked ? 1 : 0, false, false, &n_in, a.phase, a.n_phases);
-            const int2 *l_mask = diag_masked ? tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, 2, false, false, &n_mask, a.phase, a.n_phases) : nullptr;
+            const int2 *l_in = tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, diag_masked ? 1 : 0, false, false, &n_in, a.phase, a.n_phases, a.phase_w);
+            const int2 *l_mask = diag_masked ? tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, 2, false, false, &n_mask, a.phase, a.n_phases, a.phase_w) : nullptr;
             if (!l_in && n_in < 0 && a.n_phases <= 1 && !diag_masked) {
                 // (formula order: HSD_SUPERTILE=1 or the list could not be allocated)
                 n_in = (int)nb;
@@ -2117,16 +2101,10 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                 b.stamps = nullptr;
                 if (a.tau) {
                     b.dbg &= ~8;                          // (the lifetime stamps are a matrix-launch hook)
-                    // per-tile maxima of this launch's thresholds (they tighten between the phases of a sweep): rows [i_begin,
+                    // this launch's thresholds (they tighten between the phases of a sweep) as bfloat16, rounded up: rows [i_begin,
                     // i_end) carry thresholds; the columns as well when the region is mirrored onto itself
-                    b.ttau_i = LI.d_ttau; b.ttau_j = LJ.d_ttau;
                     hipLaunchKernelGGL(tau_bf16_up_kernel, dim3((unsigned)((a.i_end - a.i_begin + 255) / 256)), dim3(256), 0, stream, a.tau, a.i_begin, a.i_end,
                                        const_cast<uint16_t *>(a.tau16));
-                    hipLaunchKernelGGL(list_granule_tau_kernel, dim3((unsigned)((LI.ntiles * 8 + 255) / 256)), dim3(256), 0, stream, LI.d_gl, LI.ntiles * 8, a.tau,
-                                       a.i_begin, a.i_end, LI.d_ttau);
-                    if (!a.sym)
-                        hipLaunchKernelGGL(list_granule_tau_kernel, dim3((unsigned)((LJ.ntiles * 8 + 255) / 256)), dim3(256), 0, stream, LJ.d_gl, LJ.ntiles * 8, a.tau,
-                                           a.mirror ? a.j_begin : (int64_t)0, a.mirror ? a.j_end : (int64_t)0, LJ.d_ttau);
                 }
                 if (n_in > 0) {
                     if (a.tau)
@@ -2199,7 +2177,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
     a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, nullptr);
     if (a.n_phases > 1) {
         int cnt = -1;
-        a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &cnt, a.phase, a.n_phases);
+        a.tiles = tile_order(ctx, a.tiles_i, a.tiles_j, a.sym, 0, false, false, &cnt, a.phase, a.n_phases, a.phase_w);
         if (cnt < 0) return hsd_fail(ctx, HSD_ERR_HIP, "tile list of a sweep phase could not be allocated");
         a.ntiles = cnt;
         if (cnt == 0) return HSD_OK;
@@ -3131,11 +3109,32 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     // its k best and tightens its threshold, so that the candidates appended per row fall from ~ k n / M to
     // ~ k n / (M P) + k (1 + 1/2 + .. + 1/(P-1)).  HSD_TOPK_PHASES forces a count (tests).
     int n_phases = 1;
+    // A sweep that earns eight phases takes them GEOMETRICALLY instead: 1/32, 1/32, 1/16, 1/8, 1/4, 1/2 of the tile groups
+    // (residues [0,1), [1,2), [2,4), [4,8), [8,16), [16,32) of the anti-diagonal index mod 32).  What phases save are appends
+    // (~0.09 ms per million at BA N = 100k), and appends are (columns of the launch) x k / (columns the thresholds have seen): the
+    // loose first thresholds -- from a 1 % sample -- then meet 3 % of the columns instead of 12.5 % (61 instead of 244 appends per
+    // row), and every later launch doubles what the thresholds know.  Lists are compacted (0.42 ms) where that saves more in the
+    // next launch than it costs -- after the first and the fourth -- and after the fifth: rows whose k-th distance is shared by thousands of
+    // columns (leaves of a scale-free graph with identical rings: the integer distances tie exactly) append every one of them, and the
+    // last launch alone covers half the columns (without it 4 of 100 000 rows overflowed 2 048 entries and the call was repeated).
+    // HSD_TOPK_GEOM=0|1: never / also for small sweeps (tests).
+    bool geometric = false;
     {
         const int64_t t128 = (rows + 127) / 128, tiles = t128 * ((n + 127) / 128);
         const int cus = std::max(1, ctx->prop.multiProcessorCount);
         while (n_phases < 8 && tiles / (2 * n_phases) >= 64 * (int64_t)cus) n_phases *= 2;
-        if (const char *ep = getenv("HSD_TOPK_PHASES")) n_phases = std::max(1, std::min(16, atoi(ep)));
+        geometric = n_phases == 8;
+        if (const char *ep = getenv("HSD_TOPK_PHASES")) { n_phases = std::max(1, std::min(16, atoi(ep))); geometric = false; }
+        if (const char *eg = getenv("HSD_TOPK_GEOM")) geometric = atoi(eg) != 0;
+    }
+    struct Launch { int lo, w, mod; bool compact_after; };
+    std::vector<Launch> sched;
+    if (geometric) {
+        sched = {{0, 1, 32, true}, {1, 1, 32, false}, {2, 2, 32, false}, {4, 4, 32, true}, {8, 8, 32, true}, {16, 16, 32, false}};
+        n_phases = 32;                                // (the list capacity below is sized by the first launch's share)
+    } else {
+        // equal phases; the thresholds tighten fastest early on: compact after phases 1, 2, 4, ... (phases 5-8 of 8 together append ~k entries)
+        for (int ph = 0; ph < n_phases; ++ph) sched.push_back({ph, 1, n_phases, ph + 1 < n_phases && ((ph + 1) & ph) == 0});
     }
     // list capacity: the expected candidates of the first phase (k / M of a row's n / P columns) with room for rows of many
     // equal distances (the integer zero-pad distances tie by the hundred); an overflow anywhere costs a whole retry
@@ -3193,20 +3192,20 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
             hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, Ms, r0, rows, k, slack, d_tau - r0);
         }
         // 2. sweep: square on the diagonal (both rows of a pair are ours) + the blocks left and right of it
-        for (int ph = 0; ph < n_phases && rc == HSD_OK && e == hipSuccess; ++ph) {
+        for (size_t li = 0; li < sched.size() && rc == HSD_OK && e == hipSuccess; ++li) {
+            const Launch &L = sched[li];
             PairArgs b = a;
             b.out = nullptr; b.ld = 0;
             b.tau = d_tau - r0; b.cand_cnt = d_cnt - r0; b.cand_idx = d_idx - r0 * cap; b.cand_val = d_val - r0 * cap; b.cand_cap = (int)cap;
             b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16) - r0;
-            b.phase = ph; b.n_phases = n_phases;
+            b.phase = L.lo; b.phase_w = L.w; b.n_phases = L.mod;
             b.j_begin = r0; b.j_end = r1; b.sym = 1; b.mirror = 1; b.swap = 0;
             const int BT = tile_edge(ctx);
             rc = launch_region(ctx, b, BT, ctx->stream);
             b.sym = 0; b.mirror = 0;
             if (rc == HSD_OK && r0 > 0) { b.j_begin = 0; b.j_end = r0; rc = launch_region(ctx, b, BT, ctx->stream); }
             if (rc == HSD_OK && r1 < n) { b.j_begin = r1; b.j_end = n; rc = launch_region(ctx, b, BT, ctx->stream); }
-            // the thresholds tighten fastest early on: compact after phases 1, 2, 4, ... (phases 5-8 of 8 together append ~k entries)
-            if (rc == HSD_OK && ph + 1 < n_phases && ((ph + 1) & ph) == 0)
+            if (rc == HSD_OK && L.compact_after)
                 hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), (size_t)4 * k * 12, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, slack, d_tau);
         }
         // 3. select

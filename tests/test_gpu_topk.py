@@ -70,10 +70,11 @@ def test_topk_all_ties_and_errors(engine):
 
 
 @pytest.mark.parametrize("mode,k", [((0, 1, 0, 1), 10), ((0, 0, 0, 2), 16), ((2, 0, 0, 2), 5)])
-@pytest.mark.parametrize("phases", ["1", "3", "8"])
+@pytest.mark.parametrize("phases", ["1", "3", "8", "geom"])
 def test_topk_phased_sweep_on_the_persistent_kernel(engine, mode, k, phases):
     """The large-N schedule at a size the full matrix can check: persistent kernel (HSD_STREAM=1) with its
-    candidate epilogue, the sweep cut into phases with the thresholds tightened in between."""
+    candidate epilogue, the sweep cut into phases with the thresholds tightened in between ("geom": the geometric
+    schedule a sweep of BA N = 100k takes -- 1/32, 1/32, 1/16, 1/8, 1/4, 1/2 of the tile groups)."""
     import os
     from hsd_amd.graph import erdos_renyi, connect_components
     n = 3301
@@ -84,7 +85,7 @@ def test_topk_phased_sweep_on_the_persistent_kernel(engine, mode, k, phases):
     D = engine.pair_rows_host()
     ridx, rval = _reference_topk(D, k)
     os.environ["HSD_STREAM"] = "1"
-    os.environ["HSD_TOPK_PHASES"] = phases
+    os.environ.update({"HSD_TOPK_GEOM": "1"} if phases == "geom" else {"HSD_TOPK_PHASES": phases})
     try:
         idx, val = engine.pair_topk(k)
         a, b = 1024, 2560                                  # an aligned row block: square + both rectangles, all phased
@@ -92,6 +93,7 @@ def test_topk_phased_sweep_on_the_persistent_kernel(engine, mode, k, phases):
     finally:
         os.environ.pop("HSD_STREAM", None)
         os.environ.pop("HSD_TOPK_PHASES", None)
+        os.environ.pop("HSD_TOPK_GEOM", None)
     assert np.array_equal(val, rval)
     assert np.array_equal(idx, ridx)
     assert np.array_equal(idx2, ridx[a:b])

@@ -33,7 +33,7 @@ def soak(eng, seed=1, budget_s=90.0, max_calls=None, n_max=5000):
         cols = np.arange(n)
         for _ in range(2):
             k = int(rng.integers(1, min(n - 1, 70)))
-            env = dict(HSD_TOPK_PHASES=str(int(rng.integers(1, 9))))
+            env = dict(HSD_TOPK_PHASES=str(int(rng.integers(1, 9)))) if rng.random() < 0.75 else dict(HSD_TOPK_GEOM="1")   # equal / geometric phases
             if rng.random() < 0.6: env["HSD_STREAM"] = "1"
             if rng.random() < 0.2: env["HSD_TOPK_CAP"] = str(k + int(rng.integers(1, 40)))
             if rng.random() < 0.3: env["HSD_GRAN_SORT"] = "0"
