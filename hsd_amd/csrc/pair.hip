@@ -2587,7 +2587,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         std::vector<uint32_t> rmax_sel((size_t)nl_hist * ngran, 0u), rmax16_sel((size_t)nl_hist * ngran16, 0u);
         for (int sgi = 0; sgi < nl_hist; ++sgi) {
             tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0, 0, -1};
-            list_cap += (bin_words + 7) / 8 + 2;        // either kernel: chunks of 32 / 16 words (uint32) or 16 / 8 columns (fp64)
+            list_cap += (bin_words + CH - 1) / CH + 2;  // either kernel: chunks of CH words; no form of a layer is longer than its bin form
         }
         // Tile order and thresholds are chosen together.  A tile side of the persistent kernel is eight 16-node granules that
         // are consecutive in the graph's granule order; with R(t) the most members above a layer's threshold among a tile's
@@ -2835,7 +2835,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     }
     if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {
         ctx->list_cap = 1;
-        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + 7) / 8 + 2;
+        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + CH - 1) / CH + 2;
     }
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
     HSD_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tab, tab, (size_t)nsg * sizeof(HsdSegDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -3109,7 +3109,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     // its k best and tightens its threshold, so that the candidates appended per row fall from ~ k n / M to
     // ~ k n / (M P) + k (1 + 1/2 + .. + 1/(P-1)).  HSD_TOPK_PHASES forces a count (tests).
     int n_phases = 1;
-    // A sweep that earns eight phases takes them GEOMETRICALLY instead: 1/32, 1/32, 1/16, 1/8, 1/4, 1/2 of the tile groups
+    // HSD_TOPK_GEOM=1 (opt-in, measured): the launches GEOMETRICALLY instead of in equal phases: 1/32, 1/32, 1/16, 1/8, 1/4, 1/2 of the tile groups
     // (residues [0,1), [1,2), [2,4), [4,8), [8,16), [16,32) of the anti-diagonal index mod 32).  What phases save are appends
     // (~0.09 ms per million at BA N = 100k), and appends are (columns of the launch) x k / (columns the thresholds have seen): the
     // loose first thresholds -- from a 1 % sample -- then meet 3 % of the columns instead of 12.5 % (61 instead of 244 appends per
@@ -3117,15 +3117,18 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     // next launch than it costs -- after the first and the fourth -- and after the fifth: rows whose k-th distance is shared by thousands of
     // columns (leaves of a scale-free graph with identical rings: the integer distances tie exactly) append every one of them, and the
     // last launch alone covers half the columns (without it 4 of 100 000 rows overflowed 2 048 entries and the call was repeated).
-    // HSD_TOPK_GEOM=0|1: never / also for small sweeps (tests).
+    // Zero-pad distance: 20.1 -> 19.4-19.9 ms at BA N = 100k, 71.7 -> 66.3 ms at N = 200k.  NOT the default: rows whose distances to
+    // most columns lie in a narrow band just above their k-th (hubs against the leaves) keep a threshold inside that band after a
+    // first launch that shows them only 3 % of the columns, and append thousands in the launches that follow -- raw fp64 W1 at BA
+    // N = 100k: 1 956 rows overflow 2 048 entries (longest list 7 663) and the call is repeated at twice the price (equal phases:
+    // longest list 441).
     bool geometric = false;
     {
         const int64_t t128 = (rows + 127) / 128, tiles = t128 * ((n + 127) / 128);
         const int cus = std::max(1, ctx->prop.multiProcessorCount);
         while (n_phases < 8 && tiles / (2 * n_phases) >= 64 * (int64_t)cus) n_phases *= 2;
-        geometric = n_phases == 8;
-        if (const char *ep = getenv("HSD_TOPK_PHASES")) { n_phases = std::max(1, std::min(16, atoi(ep))); geometric = false; }
-        if (const char *eg = getenv("HSD_TOPK_GEOM")) geometric = atoi(eg) != 0;
+        if (const char *ep = getenv("HSD_TOPK_PHASES")) n_phases = std::max(1, std::min(16, atoi(ep)));
+        else if (const char *eg = getenv("HSD_TOPK_GEOM")) geometric = atoi(eg) != 0;
     }
     struct Launch { int lo, w, mod; bool compact_after; };
     std::vector<Launch> sched;
