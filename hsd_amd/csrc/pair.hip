@@ -22,8 +22,10 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 #include <type_traits>
 
 namespace {
@@ -2449,6 +2451,16 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     const int64_t n = p.n, npad = p.npad;
     const int B = p.B;
     int rc;
+    // HSD_PLAN_VERBOSE: wall time of the stages (synchronising: measurement only)
+    const bool vt = getenv("HSD_PLAN_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!vt) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hsd plan] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // the exact integer path needs integral supports and sums that fit uint32:
     //   sum_c |U_i - U_j| <= (sum of member values of ring_k(i)) + (same for j) <= 2 * sum_v value(v)
     bool use_u32 = ctx->support_integral;
@@ -2485,6 +2497,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             hipLaunchKernelGGL(prep_zp_kernel<double>, grid, block, 0, ctx->stream, p, x0.as<double>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    mark("support check + bin columns");
     HsdSegDesc *tab = ctx->seg_tab;
     for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0, 0, -1};
     ctx->dcols_alg = nl_hist * B;
@@ -2507,6 +2520,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         HSD_HIP(ctx, hipMemcpyAsync(cmax.data(), cmaxd.p, cmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
+        mark("column maxima");
         // uint16 packing: two columns per word, one v_sad_u16 covers both.  A column whose values (tail count x bin
         // width) reach 65536 is split into columns of smaller width (|T_i - T_j| (d1 + d2) is the sum of both parts).
         const char *e16 = getenv("HSD_SAD16");
@@ -2581,6 +2595,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             HSD_HIP(ctx, hipMemcpyAsync(gmax16.data(), dgm.p, gmax16.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // temporaries leave scope
         }
+        mark("members above candidates");
         int col = nl_hist * bin_stride;
         int list_cap = 1;
         std::vector<int> first_bin((size_t)nl_hist, 0);
@@ -2606,10 +2621,10 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             const bool may_sort = !(es && atoi(es) == 0) && G16 >= 16;
             const int64_t NT = std::max<int64_t>(1, G16 / 8);     // tiles of eight granules (a last, shorter group counts as one)
             std::vector<int32_t> order((size_t)G16);
-            std::vector<uint32_t> tm((size_t)((G16 + 7) / 8));
             auto plan_for = [&](const std::vector<int32_t> &ord, std::vector<LayerPlan> &plan) -> double {
                 double total = 0.0;
                 const int64_t nt = (G16 + 7) / 8;
+                std::vector<uint32_t> tm((size_t)nt);             // (per call: candidate orders are evaluated on several host threads)
                 for (int sgi = 0; sgi < nl_hist; ++sgi) {
                     LayerPlan bp{-1, 0, 0.97 * bin_words};
                     for (int q = 0; q < NC; ++q) {
@@ -2649,16 +2664,35 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             best_plan = plan;
             best_order = order;
             if (may_sort) {
-                for (int ks = 0; ks < nl_hist; ++ks)
-                    for (int kq = 0; kq < NC; ++kq) {
-                        const uint32_t *key = gmax16.data() + ((size_t)ks * NC + kq) * ngran16;
-                        for (int64_t g = 0; g < G16; ++g) order[(size_t)g] = (int32_t)g;
-                        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
-                        const double total = plan_for(order, plan);
-                        if (total < 0.99 * best_total) { best_total = total; best_plan = plan; best_order = order; best_sorted = true; }
+                // one candidate order per (layer, threshold) key: sorted and priced independently (host threads: 24 orders x 24
+                // (layer, threshold) prices took 13 of the 17.6 ms of a warm hsd_pair_prepare at BA N = 100k on one core), then
+                // compared in the fixed order of the keys
+                const int n_task = nl_hist * NC;
+                std::vector<std::vector<int32_t>> t_order((size_t)n_task);
+                std::vector<std::vector<LayerPlan>> t_plan((size_t)n_task, std::vector<LayerPlan>((size_t)nl_hist));
+                std::vector<double> t_total((size_t)n_task, 0.0);
+                const int n_thr = std::max(1, std::min<int>(std::min(n_task, 16), (int)std::thread::hardware_concurrency()));
+                auto work = [&](int t0) {
+                    for (int task = t0; task < n_task; task += n_thr) {
+                        const uint32_t *key = gmax16.data() + (size_t)task * ngran16;        // task = ks * NC + kq
+                        std::vector<int32_t> &ord = t_order[(size_t)task];
+                        ord.resize((size_t)G16);
+                        for (int64_t g = 0; g < G16; ++g) ord[(size_t)g] = (int32_t)g;
+                        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+                        t_total[(size_t)task] = plan_for(ord, t_plan[(size_t)task]);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+                work(0);
+                for (auto &th : pool) th.join();
+                for (int task = 0; task < n_task; ++task)
+                    if (t_total[(size_t)task] < 0.99 * best_total) {
+                        best_total = t_total[(size_t)task]; best_plan = t_plan[(size_t)task]; best_order = t_order[(size_t)task]; best_sorted = true;
                     }
             }
         }
+        mark("order + thresholds (host)");
         ctx->gran_order.clear();
         if (best_sorted) ctx->gran_order = best_order;
         int suf_rows = 1;                                         // row 0: zeros
@@ -2724,6 +2758,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                                             (size_t)B * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
             ctx->mode = PAIR_SAD_U32;
         }
+        mark("operand matrix + packing");
         for (int s = 0; s <= nl_hist; ++s) ctx->seg_begin[s] = s * bin_stride;
         bool any_rank = false;
         for (int sgi = 0; sgi < nl_hist; ++sgi) any_rank |= tab[sgi].rank_col0 >= 0;
@@ -2746,6 +2781,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
         }
+        mark("rank columns + suffix sums");
         // ---- uint8 ranges (persistent kernel).  Most values of a rank-form range are small: ring 2 of a scale-free graph has a
         // handful of hubs in front of hundreds of ordinary members, and its tail counts fall below 256 a few bins up.  v_sad_u8
         // takes four such columns per instruction where v_sad_u16 takes two.  Per layer: keep the first b8 low-bin words and the
@@ -2833,6 +2869,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                         best_b, best_r, nb8, d.r8_cap, best_save);
         }
     }
+    mark("byte ranges");
     if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {
         ctx->list_cap = 1;
         for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + CH - 1) / CH + 2;
