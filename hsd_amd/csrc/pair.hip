@@ -37,7 +37,7 @@ namespace {
 #define HSD_STORE_BITS "nt"     // cache-policy bits of the persistent kernel's result stores (measured: see DESIGN.md section 5)
 #endif
 #ifndef HSD_ABLATE
-#define HSD_ABLATE 0            // measurement builds only: bit 0: the mirrored half without the accumulator exchange (wrong results)
+#define HSD_ABLATE 0            // measurement builds only (wrong results): bit 0: no accumulator exchange; bits 2 / 3: only the direct / mirrored half is stored
 #endif
 #ifndef HSD_STAMPS
 #define HSD_STAMPS 0                // 1: the persistent kernel carries its in-kernel cycle stamps (HSD_DEBUG bit 3) and the plain-store switch
@@ -1056,6 +1056,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         const int lv = lane(), lyv = lv >> 3, lxv = lv & 7;
         const uint32_t ld8 = (uint32_t)a.ld * 8u;
         if (g >= 4 && !gmirror) return 0;
+#if HSD_ABLATE & 4
+        if (g >= 4) return 0;                         // measurement build: the direct half only
+#endif
+#if HSD_ABLATE & 8
+        if (g < 4) return 0;                          // measurement build: the mirrored half only
+#endif
         auto put = [&](auto NT_) __attribute__((always_inline)) {
             constexpr bool NTS = decltype(NT_)::value;
             const uint32_t vd0 = (uint32_t)(2 * lyv) * ld8 + (uint32_t)(16 * lxv);
