@@ -38,6 +38,30 @@ __global__ __launch_bounds__(256, 2) void k(double *out, long ld, int tiles_per_
     if (l == 0) cyc[blockIdx.x * 4 + w] = t1 - t0;
 }
 
+// "Quad-transposed" mirrored half: after a 4 x 4 exchange between the lanes of a quad and the four row-granule tuples, a store instruction
+// holds 2 rows x 4 lines, the QUAD lanes in one row but in four different 128-byte lines (16 bytes each, same offset), bits 3-5 the
+// 16-byte piece.  spread: distance of the four lines in granules (1: adjacent lines, 37: scattered).
+__global__ __launch_bounds__(256, 2) void kq(double *out, long ld, int tiles_per_wg, int tiles_j, unsigned long long *cyc, int spread) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = l & 3, rsel = (l >> 2) & 1, piece = l >> 3;
+    v2d v = {1.0 + threadIdx.x, 2.0 + blockIdx.x};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < tiles_per_wg; ++t) {
+        const long tile = (long)blockIdx.x * tiles_per_wg + t;
+        const long i0 = (tile / tiles_j) * 128, j0 = (tile % tiles_j) * 128 + 128 * (tile / tiles_j + 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long mrow = j0 + (w & 1) * 64 + 16 * q + 2 * (r >> 1) + 8 * rsel + (r & 1);
+                const long mcol = i0 + (w >> 1) * 64 + (long)16 * ((g * spread) % 61) + 2 * piece;
+                __builtin_nontemporal_store(v, (gv2d *)(out + mrow * ld + mcol));
+            }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (l == 0) cyc[blockIdx.x * 4 + w] = t1 - t0;
+}
+
 int main(int argc, char **argv) {
     const long n = 65536;
     double *out; if (hipMalloc(&out, (size_t)n * n * 8) != hipSuccess) { puts("alloc failed"); return 1; }
@@ -76,6 +100,16 @@ int main(int argc, char **argv) {
             if (mode == 3) gbs = (double)grid * tiles * 2 * 128 * 128 * 8 / (ms * 1e-3) / 1e9;
         }
         printf("%-30s %6.0f / %6.0f / %6.0f   (%7.1f GB/s)\n", mp.name, res[0], res[1], res[2], gbs);
+    }
+    for (int spread : {1, 37}) {
+        hipLaunchKernelGGL(kq, dim3(grid), dim3(256), 0, 0, out, n, tiles, tiles_j, d_cyc, spread);
+        hipLaunchKernelGGL(kq, dim3(grid), dim3(256), 0, 0, out, n, tiles, tiles_j, d_cyc, spread);
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)grid * 4);
+        (void)hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost);
+        double c = 0; for (auto x : h) c += (double)x;
+        printf("quad-transposed mirrored half (quad = 1 row x 4 lines, lines %2d granules apart): %6.0f cycles per store instruction per wave\n", spread,
+               c / h.size() / (tiles * 32.0));
     }
     return 0;
 }
