@@ -761,6 +761,16 @@ __device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t 
 
 // TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
 // candidate list instead of being stored (a separate instantiation: the matrix kernels' code is not touched by it).
+// The persistent kernel's lane map: lane bits (x0 y0 x1 y1 x2 y2) -> (ly, lx).  Any bijection serves the arithmetic (the LDS operand
+// reads broadcast over the other coordinate either way); the result stores decide.  A store instruction holds its wave for as long as
+// its data takes to leave the SIMD, and that grows with the number of 64-byte segments its lane QUADS touch (tools_dev/
+// ubench_store_map.hip, cycles per instruction and wave: quad in one segment 102, in two 129, in four 257).  With lx in the low lane
+// bits the direct half is at 102 and the mirrored half (there lx picks the row) at 257; interleaved, both halves are at 129.
+// 15.15 -> 14.74 ms at BA N = 100k (measured at no gain earlier in the round, when the lane exchange and the store bursts still
+// hid it).
+__device__ inline int lane_y(int l) { return ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4); }
+__device__ inline int lane_x(int l) { return (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4); }
+
 template <int KIND, int NW, bool TOPK = false>
 __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs a) {
     using T = typename Elem<KIND>::type;
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     };
 
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int ly = l >> 3, lx = l & 7;
+    const int ly = lane_y(l), lx = lane_x(l);
     const int wi = (w >> 1) * 64 + 2 * ly, wj = (w & 1) * 64 + 2 * lx;
     // The lane id as the compiler cannot see through: everything derived from it at a point of use (LDS addresses of the
     // per-tile tables and vectors, request offsets, store offsets) is then formed there, instead of being hoisted out of the
@@ -1053,7 +1063,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) { GI[qq] = 4 * (w >> 1) + qq; GJ[qq] = 8 + 4 * (w & 1) + qq; }
         }
-        const int lv = lane(), lyv = lv >> 3, lxv = lv & 7;
+        const int lv = lane(), lyv = lane_y(lv), lxv = lane_x(lv);
         const uint32_t ld8 = (uint32_t)a.ld * 8u;
         if (g >= 4 && !gmirror) return 0;
 #if HSD_ABLATE & 4
@@ -1115,7 +1125,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     auto init_acc = [&](int buf) __attribute__((always_inline)) {
         if (gpoint) {
             double pj[TC];
-            const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
+            const int lv = lane(), wi = (w >> 1) * 64 + 2 * lane_y(lv), wj = (w & 1) * 64 + 2 * lane_x(lv);
             const double *ax = aux + (buf * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
             for (int cc = 0; cc < TC; ++cc) pj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
@@ -1322,7 +1332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     // accumulator sets are live), and a spill here is a scratch reload that waits behind every outstanding
                     // operand request.
                     const double *ax = aux + (cur * a.n_aux + seg) * AUX_STRIDE;      // 1/ring size, staged with the tile
-                    const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
+                    const int lv = lane(), wi = (w >> 1) * 64 + 2 * lane_y(lv), wj = (w & 1) * 64 + 2 * lane_x(lv);
                     double vj_[TC];
 #pragma unroll
                     for (int cc = 0; cc < TC; ++cc) vj_[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
@@ -1410,7 +1420,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         // ---- epilogue arithmetic ----
         if constexpr (KIND == K_DOT) {
             double hj[TC];
-            const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
+            const int lv = lane(), wi = (w >> 1) * 64 + 2 * lane_y(lv), wj = (w & 1) * 64 + 2 * lane_x(lv);
             const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
             for (int cc = 0; cc < TC; ++cc) hj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
@@ -1426,7 +1436,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         }
         if (!SEG && gpoint) {
             double pj[TC];
-            const int lv = lane(), wi = (w >> 1) * 64 + 2 * (lv >> 3), wj = (w & 1) * 64 + 2 * (lv & 7);
+            const int lv = lane(), wi = (w >> 1) * 64 + 2 * lane_y(lv), wj = (w & 1) * 64 + 2 * lane_x(lv);
             const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
 #pragma unroll
             for (int cc = 0; cc < TC; ++cc) pj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
