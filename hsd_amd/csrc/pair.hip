@@ -310,6 +310,16 @@ __device__ inline int plan_segment(const SegDesc &sd, bool active, uint32_t R, i
     return emit_chunks<CH>(nch, col0, words, l, lst);
 }
 
+// The pair kernels' lane map: lane bits (x0 y0 x1 y1 x2 y2) -> (ly, lx).  Any bijection serves the arithmetic (the LDS operand
+// reads broadcast over the other coordinate either way); the result stores decide.  A store instruction holds its wave for as long as
+// its data takes to leave the SIMD, and that grows with the number of 64-byte segments its lane QUADS touch (tools_dev/
+// ubench_store_map.hip, cycles per instruction and wave: quad in one segment 102, in two 129, in four 257).  With lx in the low lane
+// bits the direct half is at 102 and the mirrored half (there lx picks the row) at 257; interleaved, both halves are at 129.
+// Persistent kernel: 15.15 -> 14.74 ms at BA N = 100k (measured at no gain earlier in the round, when the lane exchange and the
+// store bursts still hid it); the one-tile kernel takes the same map (ER N = 10k is bound by its stores).
+__device__ inline int lane_y(int l) { return ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4); }
+__device__ inline int lane_x(int l) { return (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4); }
+
 // A workgroup computes exactly one tile.
 template <int KIND, bool FAST, int TR>
 __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArgs a) {
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
     int *nlist_p = reinterpret_cast<int *>(clist + a.list_cap);
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int ly = l >> 3, lx = l & 7;
+    const int ly = lane_y(l), lx = lane_x(l);
     // Lane (ly, lx) of wave w owns rows  wi + 16 (r>>1) + (r&1)  and columns  wj + 16 (c>>1) + (c&1),
     // r, c < TR: adjacent pairs interleaved over the 8 lanes of a group.  With this map a store
     // instruction -- direct (fixed r, column pair) or mirrored (fixed c, row pair) -- has each
@@ -761,16 +771,6 @@ __device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t 
 
 // TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
 // candidate list instead of being stored (a separate instantiation: the matrix kernels' code is not touched by it).
-// The persistent kernel's lane map: lane bits (x0 y0 x1 y1 x2 y2) -> (ly, lx).  Any bijection serves the arithmetic (the LDS operand
-// reads broadcast over the other coordinate either way); the result stores decide.  A store instruction holds its wave for as long as
-// its data takes to leave the SIMD, and that grows with the number of 64-byte segments its lane QUADS touch (tools_dev/
-// ubench_store_map.hip, cycles per instruction and wave: quad in one segment 102, in two 129, in four 257).  With lx in the low lane
-// bits the direct half is at 102 and the mirrored half (there lx picks the row) at 257; interleaved, both halves are at 129.
-// 15.15 -> 14.74 ms at BA N = 100k (measured at no gain earlier in the round, when the lane exchange and the store bursts still
-// hid it).
-__device__ inline int lane_y(int l) { return ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4); }
-__device__ inline int lane_x(int l) { return (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4); }
-
 template <int KIND, int NW, bool TOPK = false>
 __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs a) {
     using T = typename Elem<KIND>::type;
