@@ -5,20 +5,21 @@
 //
 // Every distance on this path is a sum over columns c of f(X[c][i], Y[c][j]):
 //   W1 on raw samples (scipy)      sum_c | G[c][i] - G[c][j] |,  G = CDF * bin width      (fp64)
-//   W1 after zero-pad alignment    sum_k min(1/n_ik, 1/n_jk) * sum_c | U[c][i] - U[c][j] |,
-//                                  U = (tail count) * bin width: EXACT uint32 arithmetic,
-//                                  one v_sad_u32 per column pair
+//   W1 after zero-pad alignment    sum_k min(1/n_ik, 1/n_jk) * sum_c | U[c][i] - U[c][j] |: EXACT unsigned integers,
+//                                  two uint16 columns per v_sad_u16 (four uint8 per v_sad_u8 where a layer's values are
+//                                  small); a layer has several exact forms -- bins, ranks above a threshold, bytes -- and a
+//                                  tile pair reads the shortest (SegDesc, plan_segment*, prepare_w1_zeropad)
 //   KL / symmetric KL              H[i] - sum_c P[c][i] * logP[c][j]                       (fp64 FMA)
-// so one tiling skeleton serves all of them.  A workgroup (4 waves) owns a BT x BT tile of node
-// pairs; both operand blocks are staged CH columns at a time in LDS by direct-to-LDS loads
-// (bin-major storage makes a tile-wide slice of one column contiguous), double buffered; each
-// lane accumulates a TR x TR block of pairs in registers.  Only tiles on or above the diagonal
-// are computed; the mirrored tile is written from the same registers.
+// so one tiling skeleton serves all of them.  Four waves own a 128 x 128 (or 64 x 64) tile of node pairs; both operand
+// blocks are staged CH columns at a time in LDS by direct-to-LDS loads (bin-major storage makes a tile-wide slice of one
+// column contiguous), double buffered; each lane accumulates an 8 x 8 (4 x 4) block of pairs in registers.  Only tiles on or
+// above the diagonal of a symmetric region are computed; the mirrored tile is written from the same registers.
 //
-// Two tile shapes are built: 64 x 64 (4 x 4 pairs per lane, ~5 workgroups per CU) and 128 x 128
-// (8 x 8 pairs per lane, 2 per CU).  The small tile is the default: the kernel alternates an
-// arithmetic phase with a burst of result stores, and only independent co-resident workgroups
-// overlap the two (measured: profiles/ and DESIGN.md).
+// Two kernels: pair_stream_kernel -- persistent workgroups (two per CU) that walk granule-composed 128 x 128 tiles drawn from
+// per-XCD counters, plan the next tile while computing this one and let a finished tile's stores leave under the next tile's
+// arithmetic: every region with >= 16 tiles per resident workgroup -- and pair_kernel, one tile per workgroup: small regions
+// (64 x 64 tiles, ~5 workgroups per CU), strips at the end of a range, KL's diagonal tiles.  Both produce the same bits per
+// pair.  DESIGN.md section 5 holds the measurements behind each choice.
 #include "common.hpp"
 
 #include <algorithm>
