@@ -157,6 +157,14 @@ def test_target_ba100k_w1_resident_80gb(engine):
     a, b = 50000 - 64, 50000 + 200
     blk = engine.pair_rows_host(a, b)
     assert np.array_equal(blk, M.rows_to_host(a, b))
+    # a sum of W1 distances between empirical distributions is a metric (Variant A; the zero-pad distance, normalised per
+    # pair by the longer ring, is not): the triangle inequality over whole resident rows
+    rng = np.random.default_rng(5)
+    for i in (3, 40000, 99999):
+        ri = M.rows_to_host(i, i + 1)[0]
+        for j in rng.integers(0, n, 4):
+            rj = M.rows_to_host(int(j), int(j) + 1)[0]
+            assert np.all(ri <= ri[j] + rj + 1e-9 * (1.0 + ri))          # D(i, k) <= D(i, j) + D(j, k) for every k
     M.free()
     # Variant B at the same size: packed uint16 operands with split columns (ring sizes x bin widths
     # exceed 65535 here) against the oracle, and bit-identical to the plain uint32 kernel
@@ -178,6 +186,17 @@ def test_target_ba100k_w1_resident_80gb(engine):
         M.free()
     finally:
         os.environ.pop("HSD_SAD16", None)
+    # ... and to the packed kernel WITHOUT the uint8 ranges: which tiles may read bytes is decided by flags that only a graph
+    # with hubs exercises (a flagged granule once hid its neighbour's larger ring in the tile maximum -- at this size only)
+    os.environ["HSD_U8"] = "0"
+    try:
+        engine.pair_prepare(0, 1, 0, 2)
+        M = engine.pair_rows_device()
+        engine.sync()
+        assert M.stats()["sum"] == st16["sum"] and np.array_equal(M.rows_to_host(777, 779), rows16)
+        M.free()
+    finally:
+        os.environ.pop("HSD_U8", None)
 
 
 def test_multihsd_medium_vs_oracle(engine):
