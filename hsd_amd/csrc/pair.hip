@@ -17,7 +17,7 @@
 //
 // Two kernels: pair_stream_kernel -- persistent workgroups (two per CU) that walk granule-composed 128 x 128 tiles drawn from
 // per-XCD counters, plan the next tile while computing this one and let a finished tile's stores leave under the next tile's
-// arithmetic: every region with >= 16 tiles per resident workgroup -- and pair_kernel, one tile per workgroup: small regions
+// arithmetic: every region with >= 11 (integer kinds) / 16 (fp64) tiles per resident workgroup -- and pair_kernel, one tile per workgroup: small regions
 // (64 x 64 tiles, ~5 workgroups per CU), strips at the end of a range, KL's diagonal tiles.  Both produce the same bits per
 // pair.  DESIGN.md section 5 holds the measurements behind each choice.
 #include "common.hpp"
@@ -1996,8 +1996,11 @@ int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
     const int64_t ti = (a.i_end - a.i_begin) / 128, tj = (a.j_end - a.j_begin) / 128;
     const int64_t tiles = a.sym ? ti * (ti + 1) / 2 : ti * tj;
     if (tiles <= 0) return 0;
+    // (tools_dev/xover.py, end of round 3: the integer kinds cross over at ~11 tiles per workgroup -- zero-pad, BA N = 14k: 0.385 one-tile /
+    // 0.358 persistent, N = 16k: 0.500 / 0.376 -- the fp64 kinds within 3 % of each other between 12 and 16 tiles)
+    const int64_t per_wg = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) ? 11 : 16;
     const char *ew = getenv("HSD_STREAM");
-    if (!(ew && atoi(ew) != 0) && tiles < 16 * 2 * (int64_t)ctx->prop.multiProcessorCount) return 0;
+    if (!(ew && atoi(ew) != 0) && tiles < per_wg * 2 * (int64_t)ctx->prop.multiProcessorCount) return 0;
     return 4;
 }
 
