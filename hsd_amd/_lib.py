@@ -22,6 +22,8 @@ ERR_TOO_LARGE = -6
 ERR_COMM = -7
 ERR_NOT_NORMALISED = -8
 ERR_UNSUPPORTED = -9
+ERR_NOMEM = -10
+ERR_INTERNAL = -11
 
 METRIC_WASSERSTEIN = 0
 METRIC_KL = 1

@@ -11,21 +11,21 @@
 
 static_assert(sizeof(ncclUniqueId) == 128, "hsd.h documents a 128-byte id");
 
-extern "C" int hsd_comm_destroy_internal(hsd_ctx *ctx) {
+extern "C" int hsd_comm_destroy_internal(hsd_ctx *ctx) try {
     if (ctx && ctx->comm) {
         ncclCommDestroy(reinterpret_cast<ncclComm_t>(ctx->comm));
         ctx->comm = nullptr;
     }
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_comm_unique_id(void *id128) {
+extern "C" int hsd_comm_unique_id(void *id128) try {
     if (!id128) return HSD_ERR_INVALID;
     ncclUniqueId id;
     if (ncclGetUniqueId(&id) != ncclSuccess) return HSD_ERR_COMM;
     memcpy(id128, &id, sizeof id);
     return HSD_OK;
-}
+} HSD_ABI_GUARD(nullptr)
 
 static int check_shard(hsd_ctx *ctx, int world, int rank) {
     if (world < 1 || rank < 0 || rank >= world) return hsd_fail(ctx, HSD_ERR_INVALID, "bad world/rank %d/%d", world, rank);
@@ -50,7 +50,7 @@ static void commit_shard(hsd_ctx *ctx, int world, int rank, ncclComm_t comm) {
     ctx->hop = -1;
 }
 
-extern "C" int hsd_comm_init(hsd_ctx *ctx, int world, int rank, const void *id128) {
+extern "C" int hsd_comm_init(hsd_ctx *ctx, int world, int rank, const void *id128) try {
     HSD_CHECK_CTX(ctx);
     int rc = check_shard(ctx, world, rank);
     if (rc) return rc;
@@ -71,9 +71,9 @@ extern "C" int hsd_comm_init(hsd_ctx *ctx, int world, int rank, const void *id12
     }
     commit_shard(ctx, world, rank, comm);
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_comm_shard(hsd_ctx *ctx, int64_t *r0, int64_t *r1) {
+extern "C" int hsd_comm_shard(hsd_ctx *ctx, int64_t *r0, int64_t *r1) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "no graph uploaded");
     const int64_t rpr = ctx->world > 1 ? ctx->rows_per_rank : ctx->n;
@@ -82,9 +82,9 @@ extern "C" int hsd_comm_shard(hsd_ctx *ctx, int64_t *r0, int64_t *r1) {
     if (r0) *r0 = a;
     if (r1) *r1 = b;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_signature_allgather(hsd_ctx *ctx) {
+extern "C" int hsd_signature_allgather(hsd_ctx *ctx) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_counts) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "no signature built");
     if (ctx->world == 1 && !ctx->comm) return HSD_OK;
@@ -99,4 +99,4 @@ extern "C" int hsd_signature_allgather(hsd_ctx *ctx) {
     hsd_release_operands(ctx);
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -163,6 +165,7 @@ struct hsd_ctx {
 };
 
 int hsd_fail(hsd_ctx *ctx, int status, const char *fmt, ...);
+int hsd_guard_status(hsd_ctx *ctx, int status, const char *what) noexcept;
 // internal status (never crosses the ABI): the bit-parallel k-hop sweep could not allocate its planes
 constexpr int HSD_INT_NO_PLANES = -1000;
 
@@ -173,6 +176,13 @@ constexpr int HSD_INT_NO_PLANES = -1000;
             return hsd_fail((ctx), HSD_ERR_HIP, "%s failed: %s (%s:%d)", #call,              \
                             hipGetErrorString(e_), __FILE__, __LINE__);                      \
     } while (0)
+
+// Function-try-block handlers of every int-returning entry point: nothing leaves the C ABI as a C++ exception (a ctypes caller
+// would reach std::terminate with a GPU context open).  Usage:  extern "C" int hsd_x(hsd_ctx *ctx, ...) try { ... } HSD_ABI_GUARD(ctx)
+#define HSD_ABI_GUARD(ctx)                                                                   \
+    catch (const std::bad_alloc &) { return hsd_guard_status((ctx), HSD_ERR_NOMEM, "out of host memory"); }      \
+    catch (const std::exception &e_) { return hsd_guard_status((ctx), HSD_ERR_INTERNAL, e_.what()); }           \
+    catch (...) { return hsd_guard_status((ctx), HSD_ERR_INTERNAL, "unknown C++ exception"); }
 
 #define HSD_CHECK_CTX(ctx)                                                                   \
     do {                                                                                     \

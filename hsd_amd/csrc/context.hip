@@ -17,6 +17,13 @@ int hsd_fail(hsd_ctx *ctx, int status, const char *fmt, ...) {
     return status;
 }
 
+int hsd_guard_status(hsd_ctx *ctx, int status, const char *what) noexcept {
+    if (ctx) {
+        try { ctx->err = what; } catch (...) { ctx->err.clear(); }      // (the assignment itself may need memory)
+    }
+    return status;
+}
+
 extern "C" int hsd_abi_version(void) { return HSD_ABI_VERSION; }
 
 extern "C" const char *hsd_strerror(int status) {
@@ -31,6 +38,8 @@ extern "C" const char *hsd_strerror(int status) {
         case HSD_ERR_COMM: return "RCCL error";
         case HSD_ERR_NOT_NORMALISED: return "The sum of probability distribution must be 1.0.";
         case HSD_ERR_UNSUPPORTED: return "metric is not implemented";
+        case HSD_ERR_NOMEM: return "out of host memory";
+        case HSD_ERR_INTERNAL: return "internal error (C++ exception stopped at the ABI)";
         default: return "unknown status";
     }
 }
@@ -39,7 +48,7 @@ extern "C" const char *hsd_last_error(const hsd_ctx *ctx) { return ctx ? ctx->er
 
 extern "C" void hsd_destroy(hsd_ctx *ctx);
 
-extern "C" int hsd_create(int device, hsd_ctx **out) {
+extern "C" int hsd_create(int device, hsd_ctx **out) try {
     if (!out) return HSD_ERR_INVALID;
     *out = nullptr;
     int count = 0;
@@ -59,7 +68,7 @@ extern "C" int hsd_create(int device, hsd_ctx **out) {
     }
     *out = ctx;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(nullptr)
 
 void hsd_release_operands(hsd_ctx *ctx) {
     if (ctx->d_X) (void)hipFree(ctx->d_X);
@@ -118,7 +127,7 @@ extern "C" void hsd_destroy(hsd_ctx *ctx) {
     delete ctx;
 }
 
-extern "C" int hsd_get_device_info(hsd_ctx *ctx, hsd_device_info *out) {
+extern "C" int hsd_get_device_info(hsd_ctx *ctx, hsd_device_info *out) try {
     HSD_CHECK_CTX(ctx);
     if (!out) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
     memset(out, 0, sizeof *out);
@@ -129,56 +138,56 @@ extern "C" int hsd_get_device_info(hsd_ctx *ctx, hsd_device_info *out) {
     out->hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
     out->clock_khz = ctx->prop.clockRate;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_sync(hsd_ctx *ctx) {
+extern "C" int hsd_sync(hsd_ctx *ctx) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_malloc(hsd_ctx *ctx, size_t bytes, void **dptr) {
+extern "C" int hsd_malloc(hsd_ctx *ctx, size_t bytes, void **dptr) try {
     HSD_CHECK_CTX(ctx);
     if (!dptr) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
     *dptr = nullptr;
     HSD_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 1));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_free(hsd_ctx *ctx, void *dptr) {
+extern "C" int hsd_free(hsd_ctx *ctx, void *dptr) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (dptr) HSD_HIP(ctx, hipFree(dptr));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_memcpy_d2h(hsd_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+extern "C" int hsd_memcpy_d2h(hsd_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_memcpy_h2d(hsd_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+extern "C" int hsd_memcpy_h2d(hsd_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_memset(hsd_ctx *ctx, void *dptr, int value, size_t bytes) {
+extern "C" int hsd_memset(hsd_ctx *ctx, void *dptr, int value, size_t bytes) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_timer_start(hsd_ctx *ctx) {
+extern "C" int hsd_timer_start(hsd_ctx *ctx) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_timer_stop(hsd_ctx *ctx, float *elapsed_ms) {
+extern "C" int hsd_timer_stop(hsd_ctx *ctx, float *elapsed_ms) try {
     HSD_CHECK_CTX(ctx);
     HSD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HSD_HIP(ctx, hipEventSynchronize(ctx->ev1));
@@ -186,10 +195,10 @@ extern "C" int hsd_timer_stop(hsd_ctx *ctx, float *elapsed_ms) {
     HSD_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (elapsed_ms) *elapsed_ms = ms;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 // ---- graph ------------------------------------------------------------------------------
-extern "C" int hsd_set_graph(hsd_ctx *ctx, int64_t n, const int64_t *rowptr, const int32_t *col) {
+extern "C" int hsd_set_graph(hsd_ctx *ctx, int64_t n, const int64_t *rowptr, const int32_t *col) try {
     HSD_CHECK_CTX(ctx);
     if (n <= 0 || !rowptr) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_set_graph: n=%lld", (long long)n);
     if (n >= (int64_t)1 << 31) return hsd_fail(ctx, HSD_ERR_TOO_LARGE, "node ids must fit int32");
@@ -232,7 +241,7 @@ extern "C" int hsd_set_graph(hsd_ctx *ctx, int64_t n, const int64_t *rowptr, con
     ctx->nnz = nnz;
     ctx->h_degree.swap(deg);
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 // ---- resident-matrix checks ---------------------------------------------------------------
 __device__ inline double wave_sum(double v) {
@@ -270,7 +279,11 @@ __global__ __launch_bounds__(256) void matrix_stats_kernel(const double *__restr
     for (int64_t t = (int64_t)blockIdx.y * MS_GROUP; t < t_end; ++t) {
         int64_t j_lo, j_hi;
         bool square = false;
-        if (t < side_tiles_left) { j_lo = t * MS_TILE; j_hi = row0 < j_lo + MS_TILE ? row0 : j_lo + MS_TILE; }
+        if (t < side_tiles_left) {
+            // (a block wholly outside the square, row0 >= cols, has only left tiles: they end at the last column, not at row0)
+            const int64_t left_end = row0 < cols ? row0 : cols;
+            j_lo = t * MS_TILE; j_hi = left_end < j_lo + MS_TILE ? left_end : j_lo + MS_TILE;
+        }
         else if (t < side_tiles_left + sq_tiles) {
             const int64_t tj = t - side_tiles_left;
             if (tj < ti) continue;                                  // read by the strip that owns its mirror
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(256) void matrix_stats_kernel(const double *__restr
 }
 
 extern "C" int hsd_matrix_stats(hsd_ctx *ctx, const double *dev_block, int64_t rows, int64_t cols, int64_t ld,
-                                int64_t row0, double *stats) {
+                                int64_t row0, double *stats) try {
     HSD_CHECK_CTX(ctx);
     if (!dev_block || !stats || rows <= 0 || cols <= 0 || ld < cols || row0 < 0)
         return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_matrix_stats: bad arguments");
@@ -370,7 +383,7 @@ extern "C" int hsd_matrix_stats(hsd_ctx *ctx, const double *dev_block, int64_t r
     }
     stats[0] = (double)s; stats[1] = diag; stats[2] = asym; stats[3] = mx; stats[4] = mn;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 __global__ __launch_bounds__(256) void matrix_add_kernel(double *__restrict__ dst, int64_t ld_dst, const double *__restrict__ src,
                                                         int64_t ld_src, int64_t cols) {
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(256) void matrix_add_kernel(double *__restrict__ ds
 }
 
 extern "C" int hsd_matrix_add(hsd_ctx *ctx, double *dev_dst, int64_t ld_dst, const double *dev_src, int64_t ld_src, int64_t rows,
-                              int64_t cols) {
+                              int64_t cols) try {
     HSD_CHECK_CTX(ctx);
     if (!dev_dst || !dev_src || rows < 0 || cols < 0 || ld_dst < cols || ld_src < cols)
         return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_matrix_add: bad arguments");
@@ -391,4 +404,4 @@ extern "C" int hsd_matrix_add(hsd_ctx *ctx, double *dev_dst, int64_t ld_dst, con
     }
     HSD_HIP(ctx, hipGetLastError());
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)

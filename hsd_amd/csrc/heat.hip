@@ -485,7 +485,7 @@ static void release_heat(hsd_ctx *ctx) {
 
 extern "C" void hsd_heat_release_internal(hsd_ctx *ctx) { release_heat(ctx); }
 
-extern "C" int hsd_set_laplacian(hsd_ctx *ctx, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val) {
+extern "C" int hsd_set_laplacian(hsd_ctx *ctx, int64_t n, const int64_t *rowptr, const int32_t *col, const double *val) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "upload the graph first");
     if (n != ctx->n || !rowptr || !col || !val) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_set_laplacian: bad arguments");
@@ -534,10 +534,10 @@ extern "C" int hsd_set_laplacian(hsd_ctx *ctx, int64_t n, const int64_t *rowptr,
     }
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 extern "C" int hsd_heat_wavelets(hsd_ctx *ctx, const double *coeff, int order, double lmax, double threshold, int64_t c0,
-                                 int64_t c1, double *out, int64_t ld, int out_on_device) {
+                                 int64_t c1, double *out, int64_t ld, int out_on_device) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_lrowptr) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "hsd_set_laplacian has not been called");
     const int64_t n = ctx->n;
@@ -587,10 +587,10 @@ extern "C" int hsd_heat_wavelets(hsd_ctx *ctx, const double *coeff, int order, d
     hsd_dev_free(R);
     hsd_dev_free(d_out_stage);
     return rc;
-}
+} HSD_ABI_GUARD(ctx)
 
 extern "C" int hsd_heat_wavelets_multi(hsd_ctx *ctx, const double *coeff /* [n_scales][order+1] */, int n_scales, int order, double lmax,
-                                       double threshold, double *const *outs, int64_t ld) {
+                                       double threshold, double *const *outs, int64_t ld) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_lrowptr) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "hsd_set_laplacian has not been called");
     const int64_t n = ctx->n;
@@ -653,7 +653,7 @@ extern "C" int hsd_heat_wavelets_multi(hsd_ctx *ctx, const double *coeff /* [n_s
     hsd_dev_free(R);
     hsd_dev_free(d_coef);
     return rc;
-}
+} HSD_ABI_GUARD(ctx)
 
 // ragged rings of all nodes resident on the device (offsets + members), shared by the calls below
 static int ensure_rings(hsd_ctx *ctx, int hop) {
@@ -698,7 +698,7 @@ static int ensure_rings(hsd_ctx *ctx, int hop) {
 }
 
 extern "C" int hsd_ring_stats(hsd_ctx *ctx, int hop, const double *psi_rows_dev, int64_t ld, int64_t r0, int64_t r1, double *sums,
-                              int32_t *sizes) {
+                              int32_t *sizes) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "no graph uploaded");
     if (hop < 0 || hop >= HSD_MAX_LAYERS || r0 < 0 || r1 > ctx->n || r0 > r1 || !psi_rows_dev || ld < ctx->n || !sums)
@@ -720,11 +720,11 @@ extern "C" int hsd_ring_stats(hsd_ctx *ctx, int hop, const double *psi_rows_dev,
     if (sizes)
         for (int64_t s = 0; s < nseg; ++s) sizes[s] = (int32_t)(ctx->h_hoffsets[(size_t)(r0 * L + s + 1)] - ctx->h_hoffsets[(size_t)(r0 * L + s)]);
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 extern "C" int hsd_multiscale_ring_stats(hsd_ctx *ctx, int hop, const double *coeff /* [n_scales][order+1] */, int n_scales,
                                          int order, double lmax, double threshold, int64_t r0, int64_t r1,
-                                         double *sums /* host [n_scales][r1-r0][hop+1] */, int32_t *sizes /* host or NULL */) {
+                                         double *sums /* host [n_scales][r1-r0][hop+1] */, int32_t *sizes /* host or NULL */) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_lrowptr) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "hsd_set_laplacian has not been called");
     const int64_t n = ctx->n;
@@ -829,9 +829,9 @@ extern "C" int hsd_multiscale_ring_stats(hsd_ctx *ctx, int hop, const double *co
         for (int64_t s = 0; s < nsrc * L; ++s)
             sizes[s] = (int32_t)(ctx->h_hoffsets[(size_t)(r0 * L + s + 1)] - ctx->h_hoffsets[(size_t)(r0 * L + s)]);
     return rc;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_heat_signature_build(hsd_ctx *ctx, int hop, const double *psi_dev, int64_t ld) {
+extern "C" int hsd_heat_signature_build(hsd_ctx *ctx, int hop, const double *psi_dev, int64_t ld) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "no graph uploaded");
     if (hop < 0 || hop >= HSD_MAX_LAYERS || !psi_dev || ld < ctx->n) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_heat_signature_build: bad arguments");
@@ -895,7 +895,7 @@ extern "C" int hsd_heat_signature_build(hsd_ctx *ctx, int hop, const double *psi
     if (rc) return rc;
     if (e != hipSuccess || e2 != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "hsd_heat_signature_build: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 static int pair_heat_common(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, int64_t ld, int out_on_device, double **dst, int64_t *dld) {
     if (!ctx->d_hvalues) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_heat_signature_build has not been called");
@@ -925,7 +925,7 @@ static int pair_heat_finish(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, i
 }
 
 extern "C" int hsd_pair_heat_rows(hsd_ctx *ctx, int layer_lo, int layer_hi, int64_t r0, int64_t r1, double *out, int64_t ld,
-                                  int out_on_device) {
+                                  int out_on_device) try {
     HSD_CHECK_CTX(ctx);
     if (r0 == r1) return HSD_OK;
     double *dst;
@@ -949,10 +949,10 @@ extern "C" int hsd_pair_heat_rows(hsd_ctx *ctx, int layer_lo, int layer_hi, int6
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (flag[0] & 1) return hsd_fail(ctx, HSD_ERR_EMPTY_RING, "Distribution can't be empty.");
     return pair_heat_finish(ctx, r0, r1, out, ld, out_on_device, dst);
-}
+} HSD_ABI_GUARD(ctx)
 
 extern "C" int hsd_pair_heat_rowform(hsd_ctx *ctx, const double *psi_dev, int64_t ldpsi, int64_t r0, int64_t r1, double *out,
-                                     int64_t ld, int out_on_device) {
+                                     int64_t ld, int out_on_device) try {
     HSD_CHECK_CTX(ctx);
     if (r0 == r1) return HSD_OK;
     if (!psi_dev || ldpsi < ctx->n) return hsd_fail(ctx, HSD_ERR_INVALID, "bad psi");
@@ -981,9 +981,9 @@ extern "C" int hsd_pair_heat_rowform(hsd_ctx *ctx, const double *psi_dev, int64_
         }
     }
     return pair_heat_finish(ctx, r0, r1, out, ld, out_on_device, dst);
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_sample_distance(hsd_ctx *ctx, const double *p, int64_t np, const double *q, int64_t nq, int metric, double *out) {
+extern "C" int hsd_sample_distance(hsd_ctx *ctx, const double *p, int64_t np, const double *q, int64_t nq, int metric, double *out) try {
     HSD_CHECK_CTX(ctx);
     if (!out || np < 0 || nq < 0 || (np > 0 && !p) || (nq > 0 && !q)) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_sample_distance: bad arguments");
     if (metric < HSD_METRIC_WASSERSTEIN || metric > HSD_METRIC_SYMMETRIC_KL) return hsd_fail(ctx, HSD_ERR_UNSUPPORTED, "metric %d is not implemented.", metric);
@@ -1014,4 +1014,4 @@ extern "C" int hsd_sample_distance(hsd_ctx *ctx, const double *p, int64_t np, co
     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "hsd_sample_distance: %s", hipGetErrorString(e));
     if (status == 1) return hsd_fail(ctx, HSD_ERR_NOT_NORMALISED, "The sum of probability distribution must be 1.0.");
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)

@@ -245,7 +245,7 @@ static int check_rows(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
     return HSD_OK;
 }
 
-extern "C" int hsd_khop_sizes(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, int32_t *sizes) {
+extern "C" int hsd_khop_sizes(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, int32_t *sizes) try {
     HSD_CHECK_CTX(ctx);
     int rc = check_rows(ctx, hop, r0, r1);
     if (rc) return rc;
@@ -263,9 +263,9 @@ extern "C" int hsd_khop_sizes(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, int
     (void)hipStreamSynchronize(ctx->stream);
     hsd_dev_free(d_sizes);
     return rc;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_khop_members(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, const int64_t *offsets, int32_t *members) {
+extern "C" int hsd_khop_members(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, const int64_t *offsets, int32_t *members) try {
     HSD_CHECK_CTX(ctx);
     int rc = check_rows(ctx, hop, r0, r1);
     if (rc) return rc;
@@ -312,4 +312,4 @@ extern "C" int hsd_khop_members(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, c
     hsd_dev_free(d_mem);
     hsd_dev_free(d_sizes);
     return rc;
-}
+} HSD_ABI_GUARD(ctx)

@@ -23,9 +23,11 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 
@@ -2052,8 +2054,15 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
     const char *es = getenv("HSD_GRAN_SORT");
     const bool sorted = !ctx->gran_order.empty() && !(es && atoi(es) == 0);
     const int64_t key_end = sorted ? end : -end;                 // (the two orders of a range are cached side by side)
-    for (const auto &g : ctx->gran_lists)
-        if (g.begin == begin && g.end == key_end) { *out = g; return true; }
+    for (size_t k = 0; k < ctx->gran_lists.size(); ++k)
+        if (ctx->gran_lists[k].begin == begin && ctx->gran_lists[k].end == key_end) {
+            // least recently used first (like tile_lists): a hit moves to the back, so the lists of the call in progress are the last to go
+            const hsd_ctx::GranList hit = ctx->gran_lists[k];
+            ctx->gran_lists.erase(ctx->gran_lists.begin() + (long)k);
+            ctx->gran_lists.push_back(hit);
+            *out = hit;
+            return true;
+        }
     const int64_t g0 = begin / 16, g1 = end / 16;
     std::vector<int32_t> gl;
     gl.reserve((size_t)(g1 - g0));
@@ -2070,6 +2079,15 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
         // every hsd_pair_* call joins its streams before it returns)
         hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, L.d_gl, L.ntiles, ctx->d_rmax16,
                            ctx->ngran16, ctx->n_seg, L.d_tmax);
+    }
+    // Bounded: a caller that walks many different (r0, r1) row blocks -- the host-output loop of hsd_pair_rows takes one list per staging
+    // block -- would otherwise grow the cache without limit.  One call holds at most six lists (a row block's square and two rectangles), far
+    // below the bound; hipFree synchronises the device, so a list still read by a launch in flight is finished with before it goes.
+    constexpr size_t GRAN_LIST_CACHE = 64;
+    while (ctx->gran_lists.size() >= GRAN_LIST_CACHE) {
+        (void)hipFree(ctx->gran_lists.front().d_gl);
+        (void)hipFree(ctx->gran_lists.front().d_tmax);
+        ctx->gran_lists.erase(ctx->gran_lists.begin());
     }
     ctx->gran_lists.push_back(L);
     *out = L;
@@ -2691,21 +2709,42 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                 std::vector<std::vector<int32_t>> t_order((size_t)n_task);
                 std::vector<std::vector<LayerPlan>> t_plan((size_t)n_task, std::vector<LayerPlan>((size_t)nl_hist));
                 std::vector<double> t_total((size_t)n_task, 0.0);
-                const int n_thr = std::max(1, std::min<int>(std::min(n_task, 16), (int)std::thread::hardware_concurrency()));
-                auto work = [&](int t0) {
-                    for (int task = t0; task < n_task; task += n_thr) {
-                        const uint32_t *key = gmax16.data() + (size_t)task * ngran16;        // task = ks * NC + kq
-                        std::vector<int32_t> &ord = t_order[(size_t)task];
-                        ord.resize((size_t)G16);
-                        for (int64_t g = 0; g < G16; ++g) ord[(size_t)g] = (int32_t)g;
-                        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
-                        t_total[(size_t)task] = plan_for(ord, t_plan[(size_t)task]);
-                    }
+                const char *ept = getenv("HSD_PLAN_THREADS");    // cap of the host threads (1: everything on the calling thread)
+                int thr_cap = ept ? atoi(ept) : 16;
+                if (thr_cap < 1) thr_cap = 1;
+                const int n_thr = std::max(1, std::min<int>(std::min(n_task, thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
+                // tasks are drawn from a shared counter, so whatever threads exist (possibly none but the caller) finish them all
+                std::atomic<int> next_task{0};
+                std::atomic<bool> task_failed{false};            // nothing may leave a thread, or the C ABI, as an exception
+                auto work = [&]() noexcept {
+                    try {
+                        for (int task; (task = next_task.fetch_add(1, std::memory_order_relaxed)) < n_task;) {
+                            const uint32_t *key = gmax16.data() + (size_t)task * ngran16;        // task = ks * NC + kq
+                            std::vector<int32_t> &ord = t_order[(size_t)task];
+                            ord.resize((size_t)G16);
+                            for (int64_t g = 0; g < G16; ++g) ord[(size_t)g] = (int32_t)g;
+                            std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+                            t_total[(size_t)task] = plan_for(ord, t_plan[(size_t)task]);
+                        }
+                    } catch (...) { task_failed.store(true); }
                 };
-                std::vector<std::thread> pool;
-                for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
-                work(0);
-                for (auto &th : pool) th.join();
+                {
+                    std::vector<std::thread> pool;
+                    try {
+                        pool.reserve((size_t)n_thr);
+                        const char *eft = getenv("HSD_PLAN_THREADS_FAIL");       // test hook: creating the t-th thread fails
+                        const int fail_at = eft ? atoi(eft) : 0;
+                        for (int t = 1; t < n_thr; ++t) {
+                            if (t == fail_at) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+                            pool.emplace_back(work);
+                        }
+                    } catch (...) {
+                        // RLIMIT_NPROC / a pids limit: the threads that exist and the caller share the tasks
+                    }
+                    work();
+                    for (auto &th : pool) th.join();
+                }
+                if (task_failed.load()) return hsd_fail(ctx, HSD_ERR_NOMEM, "hsd_pair_prepare: out of host memory while pricing the granule orders");
                 for (int task = 0; task < n_task; ++task)
                     if (t_total[(size_t)task] < 0.99 * best_total) {
                         best_total = t_total[(size_t)task]; best_plan = t_plan[(size_t)task]; best_order = t_order[(size_t)task]; best_sorted = true;
@@ -2971,7 +3010,7 @@ int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int lay
 }  // namespace
 
 extern "C" int hsd_pair_prepare(hsd_ctx *ctx, int metric, int align, int layer_lo, int layer_hi, double kl_alpha,
-                                int kl_sorted) {
+                                int kl_sorted) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_counts) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "no signature built");
     if (layer_lo < 0 || layer_hi > ctx->hop || layer_lo > layer_hi)
@@ -2989,18 +3028,18 @@ extern "C" int hsd_pair_prepare(hsd_ctx *ctx, int metric, int align, int layer_l
         hsd_release_operands(ctx);
     }
     return rc;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element) {
+extern "C" int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
     if (n_columns) *n_columns = ctx->dcols_alg + ((wass && ctx->has_point) ? 1 : 0);
     if (bytes_per_element) *bytes_per_element = ctx->elem_bytes;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_pair_work(hsd_ctx *ctx, double *column_pairs) {
+extern "C" int hsd_pair_work(hsd_ctx *ctx, double *column_pairs) try {
     HSD_CHECK_CTX(ctx);
     if (!column_pairs) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
     unsigned long long w = 0;
@@ -3008,9 +3047,9 @@ extern "C" int hsd_pair_work(hsd_ctx *ctx, double *column_pairs) {
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *column_pairs = (double)w;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, int64_t ld, int out_on_device) {
+extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, int64_t ld, int out_on_device) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     const int64_t n = ctx->n;
@@ -3117,7 +3156,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 // ------------------------------------------------------------------------------------------
 // Fused k-nearest-neighbour consumer: what KNN_evaluate(dists,
@@ -3127,7 +3166,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
 //   2. sweep    : the normal tile kernel; its epilogue appends (j, v) with v <= tau_i to row i
 //   3. select   : per row the k smallest (value, index) candidates
 // Retries with a larger subset / capacity if a candidate list overflowed (heavy ties).
-extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out) {
+extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     if (ctx->mode == PAIR_KL)
@@ -3309,4 +3348,4 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
         }
     }
     return rc;
-}
+} HSD_ABI_GUARD(ctx)

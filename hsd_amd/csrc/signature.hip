@@ -21,7 +21,7 @@ static int alloc_counts(hsd_ctx *ctx, int hop, int n_bins) {
 }
 
 extern "C" int hsd_signature_build(hsd_ctx *ctx, int hop, const int32_t *node_bin, int n_bins, const double *support,
-                                   int64_t r0, int64_t r1) {
+                                   int64_t r0, int64_t r1) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "no graph uploaded");
     if (hop < 0 || hop >= HSD_MAX_LAYERS) return hsd_fail(ctx, HSD_ERR_INVALID, "hop=%d out of range", hop);
@@ -66,9 +66,9 @@ extern "C" int hsd_signature_build(hsd_ctx *ctx, int hop, const int32_t *node_bi
         if (rc) return rc;
     }
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_signature_build_degree(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) {
+extern "C" int hsd_signature_build_degree(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->n <= 0) return hsd_fail(ctx, HSD_ERR_NO_GRAPH, "no graph uploaded");
     // distinct degrees in ascending order = the support; a node's bin is the rank of its degree
@@ -85,23 +85,23 @@ extern "C" int hsd_signature_build_degree(hsd_ctx *ctx, int hop, int64_t r0, int
     std::vector<int32_t> bin((size_t)ctx->n);
     for (int64_t i = 0; i < ctx->n; ++i) bin[(size_t)i] = rank[(size_t)ctx->h_degree[(size_t)i]];
     return hsd_signature_build(ctx, hop, bin.data(), (int)support.size(), support.data(), r0, r1);
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_signature_dims(hsd_ctx *ctx, int *hop, int *n_bins) {
+extern "C" int hsd_signature_dims(hsd_ctx *ctx, int *hop, int *n_bins) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_counts) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "no signature built");
     if (hop) *hop = ctx->hop;
     if (n_bins) *n_bins = ctx->n_bins;
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_signature_support(hsd_ctx *ctx, double *support) {
+extern "C" int hsd_signature_support(hsd_ctx *ctx, double *support) try {
     HSD_CHECK_CTX(ctx);
     if (!ctx->d_counts) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "no signature built");
     if (!support) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
     std::copy(ctx->support.begin(), ctx->support.end(), support);
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
 static int rows_ok(hsd_ctx *ctx, int64_t r0, int64_t r1) {
     if (!ctx->d_counts) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "no signature built");
@@ -109,7 +109,7 @@ static int rows_ok(hsd_ctx *ctx, int64_t r0, int64_t r1) {
     return HSD_OK;
 }
 
-extern "C" int hsd_signature_get_counts(hsd_ctx *ctx, int64_t r0, int64_t r1, uint32_t *counts) {
+extern "C" int hsd_signature_get_counts(hsd_ctx *ctx, int64_t r0, int64_t r1, uint32_t *counts) try {
     HSD_CHECK_CTX(ctx);
     int rc = rows_ok(ctx, r0, r1);
     if (rc) return rc;
@@ -120,9 +120,9 @@ extern "C" int hsd_signature_get_counts(hsd_ctx *ctx, int64_t r0, int64_t r1, ui
                                 hipMemcpyDeviceToHost, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)
 
-extern "C" int hsd_signature_set_counts(hsd_ctx *ctx, int64_t r0, int64_t r1, const uint32_t *counts) {
+extern "C" int hsd_signature_set_counts(hsd_ctx *ctx, int64_t r0, int64_t r1, const uint32_t *counts) try {
     HSD_CHECK_CTX(ctx);
     int rc = rows_ok(ctx, r0, r1);
     if (rc) return rc;
@@ -134,4 +134,4 @@ extern "C" int hsd_signature_set_counts(hsd_ctx *ctx, int64_t r0, int64_t r1, co
                                 hipMemcpyHostToDevice, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HSD_OK;
-}
+} HSD_ABI_GUARD(ctx)

@@ -32,6 +32,8 @@ def _raise(lib, ctx, status):
         raise NotImplementedError(msg)                                  # tools/metrics.py:167
     if status == L.ERR_INVALID:
         raise ValueError(msg)
+    if status == L.ERR_NOMEM:
+        raise MemoryError(msg)
     raise HsdError(f"{lib.hsd_strerror(status).decode()}: {msg}")
 
 

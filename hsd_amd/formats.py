@@ -117,6 +117,17 @@ def read_label(path) -> dict:
     if not os.path.isfile(path):
         print(f"Lable file not exist, path:{path}")
         return labels
+    try:
+        with open(path, encoding="utf-8") as fin:
+            for raw in fin:                 # (a file with invalid UTF-8 raises here, inside the try, as in the reference)
+                record = raw.strip()
+                if record == "":
+                    break
+                node, label = record.split(" ")
+                labels[node] = int(label)
+    except Exception:                       # the reference's `finally: return label_dict`: partial result, no exception
+        pass
+    return labels
     with open(path, encoding="utf-8") as fin:
         for raw in fin:
             record = raw.strip()

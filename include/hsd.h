@@ -41,6 +41,8 @@ extern "C" {
 #define HSD_ERR_COMM             -7  /* RCCL failure                                   */
 #define HSD_ERR_NOT_NORMALISED   -8  /* tools/metrics.py:49-51 ValueError              */
 #define HSD_ERR_UNSUPPORTED      -9  /* tools/metrics.py:167 NotImplementedError       */
+#define HSD_ERR_NOMEM           -10  /* host allocation failed inside the library      */
+#define HSD_ERR_INTERNAL        -11  /* a C++ exception was stopped at the boundary    */
 
 /* metric names accepted by tools.metrics.calculate_distance that are on the hot path
  * (tools/metrics.py:151-192) */

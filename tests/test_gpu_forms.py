@@ -189,6 +189,27 @@ def test_uint8_ranges_bit_identical(engine, capfd):
         assert words["1"] < words["0"], words            # (rows 0..3000 of a preferential-attachment graph are its hubs: few tiles qualify)
 
 
+def test_plan_does_not_depend_on_host_threads(engine, capfd):
+    """hsd_pair_prepare prices its candidate granule orders on host threads.  Capped to the calling thread (HSD_PLAN_THREADS=1) and with the
+    creation of the third thread failing (HSD_PLAN_THREADS_FAIL=3: what RLIMIT_NPROC or a pids limit does) the call still returns a status,
+    not an exception through the C ABI, and chooses the same plan: same verbose plan line, same operand words, same matrix rows."""
+    g = _scale_free(9000 + 40, seed=5)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    seen = {}
+    for tag, env in (("default", {}), ("one", {"HSD_PLAN_THREADS": 1}), ("fail", {"HSD_PLAN_THREADS_FAIL": 3}), ("fail_first", {"HSD_PLAN_THREADS_FAIL": 1})):
+        with _Env(HSD_STREAM=1, HSD_PLAN_VERBOSE=1, **env):
+            capfd.readouterr()
+            engine.pair_prepare(0, 1, 0, 2)
+            plan = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("[hsd plan]") and "granule order" in ln]
+            rows = engine.pair_rows_host(128, 128 + 700)
+            seen[tag] = (plan, engine.pair_work(), rows)
+    for tag in ("one", "fail", "fail_first"):
+        assert seen[tag][0] == seen["default"][0] and seen[tag][0], (tag, seen[tag][0], seen["default"][0])
+        assert seen[tag][1] == seen["default"][1]
+        assert np.array_equal(seen[tag][2], seen["default"][2])
+
+
 def test_persistent_kernel_corner_shapes(engine):
     """Forced persistent kernel on shapes its size heuristic would not pick: a distance with NO histogram layer (K = 1,
     layers 0..0: tiles without operand chunks, only the ring-0 term), and a hierarchy too deep for its LDS budget

@@ -271,6 +271,27 @@ def test_matrix_stats_against_numpy(engine, rows, cols, row0):
     assert s[3] == a.max() and s[4] == a.min()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,row0", [(70, 100, 100), (130, 333, 400), (64, 65, 65)])
+def test_matrix_stats_block_without_a_square_part(engine, rows, cols, row0):
+    """row0 >= cols: the block has no square part and only 'left' tiles, the last of them partial (cols % 64 != 0).  The matrix is
+    uploaded with a padded leading dimension whose padding holds huge values: a tile that ran past the last column would see them."""
+    rng = np.random.default_rng(rows + cols)
+    a = rng.standard_normal((rows, cols))
+    ld = (cols + 15) // 16 * 16 + 16
+    padded = np.full((rows, ld), 1e300)
+    padded[:, :cols] = a
+    ptr = engine.malloc(padded.nbytes)
+    try:
+        engine.memcpy_h2d(ptr, padded, padded.nbytes)
+        s = engine.matrix_stats(ptr, rows, cols, ld, row0)
+    finally:
+        engine.free(ptr)
+    assert np.isclose(s[0], a.sum(), rtol=1e-11, atol=1e-9)
+    assert s[1] == 0.0 and s[2] == 0.0
+    assert s[3] == a.max() and s[4] == a.min()
+
+
 def test_engine_close_returns_the_hbm_of_live_matrices():
     """DeviceMatrix allocations are tracked by their Engine: close() frees the ones still alive (hsd_destroy does not know
     about hsd_malloc blocks), and a later free() / finalizer of such a matrix is a no-op."""
