@@ -112,7 +112,8 @@ struct hsd_ctx {
     std::vector<int32_t> gran_order;   // granules of the nodes [0, n - n % 128) in tile order (empty: natural order)
     uint32_t *d_suf = nullptr;         // suffix sums of the rank columns [suf_rows][npad] (row 0: zeros)
     int suf_rows = 0;
-    struct GranList { int64_t begin, end; int32_t *d_gl; uint32_t *d_tmax; int ntiles; };
+    // (up to three node ranges one after the other: the column side of a row-block launch is [0, r0) + the block's own rows + [r1, n))
+    struct GranList { int64_t r[6]; int sorted; int32_t *d_gl; uint32_t *d_tmax; int ntiles; };
     std::vector<GranList> gran_lists;
     int list_cap = 0;                  // entries of the pair kernel's per-tile chunk list (LDS)
     int *d_tile_ctr = nullptr;         // persistent pair kernel: 4 sets of 8 per-XCD tile counters

@@ -75,7 +75,7 @@ struct PairArgs {
     int n_aux;              // persistent kernel: per-node vectors (1/ring size per layer, ring-0 value, entropy) staged through
                             // LDS with every tile (0: read from global memory where they are needed)
     int sym;                // square region on the diagonal: only tiles on/above it are enumerated
-    int mirror;             // also write the transposed tile (the region's mirror image belongs to this call)
+    int mirror;             // also write the transposed tile (the region's mirror image belongs to this call); 2: per tile, bit 30 of its row index
     int swap;               // DOT below the diagonal: value(i,j) = H[j] - X_j . Y_i
     int hmode;              // DOT: 0 -> H[i] - acc ; 1 -> (H[i] + H[j] - acc) / 2
     int dcols, n_seg;
@@ -107,6 +107,7 @@ struct PairArgs {
 };
 
 enum { K_L1 = 0, K_SAD = 1, K_ZP = 2, K_DOT = 3, K_SAD16 = 4 };
+constexpr int TILE_MIRROR_FLAG = 1 << 30, TILE_INDEX_MASK = TILE_MIRROR_FLAG - 1;   // explicit tile lists of row-block launches (PairArgs::mirror == 2)
 
 template <int KIND> struct Elem { using type = double; };
 template <> struct Elem<K_SAD> { using type = uint32_t; };
@@ -936,6 +937,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         // after each, i.e. wave 0 -- and behind the next barrier the workgroup -- would stand still for a memory latency (and
         // for every operand request in flight: vmcnt(0)) at the top of every tile.
         int v = 0;
+        mti &= TILE_INDEX_MASK;                       // (row-block launches: bit 30 of a tile's row index says "also write it mirrored")
         if (w == 0) {
             const int l = lane();
             const int *p = a.gl_i + (int64_t)8 * mti + (l < 8 ? l : 0);
@@ -1455,7 +1457,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #if HSD_STAMPS
         const unsigned long long c_s0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
-        const bool mirror = a.mirror && !diag;
+        // a.mirror == 2: the launch covers a whole row block -- the rectangles beside the diagonal square (stored once) and the
+        // square's tiles on or above the diagonal, of which those above it are flagged to be written mirrored as well
+        const bool mirror = a.mirror == 2 ? ((ti >> 30) & 1) != 0 : (a.mirror && !diag);
         if constexpr (TOPK) {
           // wave 3's request for the tile's thresholds is older than the next tile's first chunk, which every wave has just waited for
           // (or nothing is left to wait for: the last tile): one barrier makes its arrival known to the other waves
@@ -2047,29 +2051,39 @@ __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, i
 }
 
 
-// The granule list of the node range [begin, end) (begin on a granule, a whole number of 128-node tiles): its granules in
-// the order hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank
-// segments.  Cached per context until the operands are released; false if it cannot be built.
-bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd_ctx::GranList *out) {
+// The granule list of up to three node ranges [r[0], r[1]) + [r[2], r[3]) + [r[4], r[5]) taken one after the other (each begins on a
+// granule and is a whole number of 128-node tiles; empty ranges are skipped): the granules of each range in the order
+// hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank segments.  Cached per
+// context until the operands are released; false if it cannot be built.
+bool gran_list_ranges(hsd_ctx *ctx, const int64_t (&r)[6], hipStream_t stream, hsd_ctx::GranList *out) {
     const char *es = getenv("HSD_GRAN_SORT");
-    const bool sorted = !ctx->gran_order.empty() && !(es && atoi(es) == 0);
-    const int64_t key_end = sorted ? end : -end;                 // (the two orders of a range are cached side by side)
-    for (size_t k = 0; k < ctx->gran_lists.size(); ++k)
-        if (ctx->gran_lists[k].begin == begin && ctx->gran_lists[k].end == key_end) {
+    const int sorted = (!ctx->gran_order.empty() && !(es && atoi(es) == 0)) ? 1 : 0;      // (the two orders of a range are cached side by side)
+    for (size_t k = 0; k < ctx->gran_lists.size(); ++k) {
+        const auto &c = ctx->gran_lists[k];
+        if (c.sorted == sorted && std::equal(r, r + 6, c.r)) {
             // least recently used first (like tile_lists): a hit moves to the back, so the lists of the call in progress are the last to go
-            const hsd_ctx::GranList hit = ctx->gran_lists[k];
+            const hsd_ctx::GranList hit = c;
             ctx->gran_lists.erase(ctx->gran_lists.begin() + (long)k);
             ctx->gran_lists.push_back(hit);
             *out = hit;
             return true;
         }
-    const int64_t g0 = begin / 16, g1 = end / 16;
+    }
     std::vector<int32_t> gl;
-    gl.reserve((size_t)(g1 - g0));
-    if (sorted) { for (int32_t g : ctx->gran_order) if (g >= g0 && g < g1) gl.push_back(g); }
-    else for (int64_t g = g0; g < g1; ++g) gl.push_back((int32_t)g);
-    if ((int64_t)gl.size() != g1 - g0 || gl.size() % 8 != 0 || gl.empty()) return false;
-    hsd_ctx::GranList L{begin, key_end, nullptr, nullptr, (int)(gl.size() / 8)};
+    int64_t want = 0;
+    for (int q = 0; q < 3; ++q) {
+        const int64_t g0 = r[2 * q] / 16, g1 = r[2 * q + 1] / 16;
+        if (g1 <= g0) continue;
+        want += g1 - g0;
+        if (sorted) { for (int32_t g : ctx->gran_order) if (g >= g0 && g < g1) gl.push_back(g); }
+        else for (int64_t g = g0; g < g1; ++g) gl.push_back((int32_t)g);
+        if ((int64_t)gl.size() != want || gl.size() % 8 != 0) return false;       // (every range a whole number of tiles)
+    }
+    if (gl.empty()) return false;
+    hsd_ctx::GranList L{};
+    std::copy(r, r + 6, L.r);
+    L.sorted = sorted;
+    L.ntiles = (int)(gl.size() / 8);
     if (hipMalloc(reinterpret_cast<void **>(&L.d_gl), gl.size() * sizeof(int32_t)) != hipSuccess) return false;
     if (hipMemcpy(L.d_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(L.d_gl); return false; }
     if (ctx->d_rmax16 && ctx->n_seg > 0) {
@@ -2092,6 +2106,12 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
     ctx->gran_lists.push_back(L);
     *out = L;
     return true;
+}
+
+// the list of one range [begin, end)
+bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd_ctx::GranList *out) {
+    const int64_t r[6] = {begin, end, 0, 0, 0, 0};
+    return gran_list_ranges(ctx, r, stream, out);
 }
 
 int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool allow_stream = true) {
@@ -2224,6 +2244,129 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
     }
     hipError_t e = launch_one_tile(ctx, a, BT, stream);
     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
+    return HSD_OK;
+}
+
+// Tile order of a ROW-BLOCK launch: nI row tiles x (nA + nI + nB) column tiles -- the rectangle left of the block's diagonal square, the
+// square, the rectangle right of it.  Of the square only the tiles on or above its diagonal are listed, those above it flagged
+// (TILE_MIRROR_FLAG in the row index) to be written mirrored as well; the rest as tile_order does: S x S groups dealt round-robin to the XCDs.
+const int2 *rowblock_tile_order(hsd_ctx *ctx, int nI, int nA, int nB, int *count) {
+    const char *e = getenv("HSD_SUPERTILE");
+    const int G = std::max(e ? atoi(e) : 8, 1);
+    const char *ed = getenv("HSD_XCD_DEAL");
+    const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
+    const int nJ = nA + nI + nB;
+    const int sym_key = 2 | (nA << 2), key = (G & 0xff) | (deal << 25);
+    for (size_t k = 0; k < ctx->tile_lists.size(); ++k) {
+        const auto &c = ctx->tile_lists[k];
+        if (c.tiles_i == nI && c.tiles_j == nJ && c.sym == sym_key && c.group == key) {
+            const hsd_ctx::TileList hit = c;
+            ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)k);
+            ctx->tile_lists.push_back(hit);
+            *count = hit.count;
+            return reinterpret_cast<const int2 *>(hit.d);
+        }
+    }
+    std::vector<int2> order;
+    order.reserve((size_t)nI * (nA + nB) + (size_t)nI * (nI + 1) / 2);
+    std::vector<size_t> group_begin;
+    for (int sr = 0; sr < nI; sr += G)
+        for (int sc = 0; sc < nJ; sc += G) {
+            const size_t at = order.size();
+            for (int ti = sr; ti < std::min(sr + G, nI); ++ti)
+                for (int tj = sc; tj < std::min(sc + G, nJ); ++tj) {
+                    const int ts = tj - nA;                           // position inside the square, if there
+                    if (ts >= 0 && ts < nI) {
+                        if (ts < ti) continue;                        // written by the mirror of (ts, ti)
+                        order.push_back(make_int2(ti | (ts > ti ? TILE_MIRROR_FLAG : 0), tj));
+                    } else order.push_back(make_int2(ti, tj));
+                }
+            if (order.size() > at) group_begin.push_back(at);
+        }
+    group_begin.push_back(order.size());
+    if (deal && group_begin.size() > 9) {
+        std::vector<int2> dealt;
+        dealt.reserve(order.size());
+        const size_t ng = group_begin.size() - 1;
+        for (size_t x = 0; x < 8; ++x)
+            for (size_t g = x; g < ng; g += 8) dealt.insert(dealt.end(), order.begin() + (long)group_begin[g], order.begin() + (long)group_begin[g + 1]);
+        order.swap(dealt);
+    }
+    *count = (int)order.size();
+    void *d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(order.size(), 1) * sizeof(int2)) != hipSuccess) { *count = -1; return nullptr; }
+    if (!order.empty() && hipMemcpy(d, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        *count = -1;
+        return nullptr;
+    }
+    if (ctx->tile_lists.size() >= 256) {
+        (void)hipFree(ctx->tile_lists.front().d);
+        ctx->tile_lists.erase(ctx->tile_lists.begin());
+    }
+    ctx->tile_lists.push_back({nI, nJ, sym_key, key, d, (int)order.size()});
+    return reinterpret_cast<const int2 *>(d);
+}
+
+// A row block [ra, re) x [0, n) of a Wasserstein matrix (a multi-GPU rank's share) as ONE persistent launch: the diagonal square
+// (tiles on / above its diagonal, mirrored) and the rectangles left and right of it in one tile list over one column-side granule
+// list [0, ra) + [ra, i_full) + [i_full, ...).  Three launches side by side (round 3) each kept their own 512 resident workgroups
+// and their own tail: at BA N = 100k, P = 8 a rank's block took 3.3 - 4.9 ms of zero-pad distance where its arithmetic is 2.6 ms, and
+// raw fp64 W1 52 - 62 ms against 50.6 (tools_dev/strong_share.py).  What is not a whole tile (< 128 rows at the end of the block,
+// < 128 columns at the end of the matrix) goes to the one-tile kernel as before.  *done = false: not applicable, nothing was launched.
+int launch_rowblock(hsd_ctx *ctx, const PairArgs &base, int64_t ra, int64_t re, bool *done) {
+    *done = false;
+    const int64_t n = ctx->n;
+    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
+    { const char *e = getenv("HSD_ROWBLOCK"); if (e && atoi(e) == 0) return HSD_OK; }       // A/B and tests: the three-launch form
+    if (!wass || ra % 128 != 0 || (ra == 0 && re == n)) return HSD_OK;
+    const int n_aux = ctx->n_seg + (base.point ? 1 : 0);
+    if (n_aux > 3) return HSD_OK;
+    const int64_t i_full = ra + (re - ra) / 128 * 128, Lb = i_full + (n - i_full) / 128 * 128;
+    if (i_full == ra) return HSD_OK;
+    PairArgs b = base;
+    b.i_begin = ra; b.i_end = i_full; b.j_begin = 0; b.j_end = Lb;
+    b.sym = 0; b.mirror = 2; b.swap = 0;
+    if (!stream_waves(ctx, b)) return HSD_OK;
+    hsd_ctx::GranList LI{}, LJ{};
+    const int64_t rj[6] = {0, ra, ra, i_full, i_full, Lb};
+    if (!gran_list(ctx, ra, i_full, ctx->stream, &LI) || !gran_list_ranges(ctx, rj, ctx->stream, &LJ)) return HSD_OK;
+    const int nI = LI.ntiles, nA = (int)(ra / 128), nB = (int)((Lb - i_full) / 128);
+    if (LJ.ntiles != nA + nI + nB) return HSD_OK;
+    int cnt = -1;
+    const int2 *order = rowblock_tile_order(ctx, nI, nA, nB, &cnt);
+    if (!order || cnt <= 0) return HSD_OK;
+    b.tiles_i = nI; b.tiles_j = LJ.ntiles;
+    b.tiles = order; b.ntiles = cnt;
+    b.tile_ctr = ctx->d_tile_ctr;
+    b.n_aux = n_aux;
+    b.gl_i = LI.d_gl; b.gl_j = LJ.d_gl;
+    b.tmax_i = LI.d_tmax; b.tmax_j = LJ.d_tmax;
+    b.ntl_i = LI.ntiles; b.ntl_j = LJ.ntiles;
+    b.suf = ctx->d_suf;
+    b.stamps = nullptr;
+    hipError_t e;
+    switch (ctx->mode) {
+        case PAIR_L1_F64: e = launch_stream<K_L1, 4>(ctx, b, ctx->stream); break;
+        case PAIR_SAD_U32: e = launch_stream<K_SAD, 4>(ctx, b, ctx->stream); break;
+        default: e = launch_stream<K_SAD16, 4>(ctx, b, ctx->stream); break;
+    }
+    if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "pair kernel launch: %s", hipGetErrorString(e));
+    *done = true;
+    // strips for the one-tile kernel (natural order, masked stores): the columns behind the last whole tile, then the rows behind
+    // the block's last whole tile against every column (both orientations of a pair give the same bits: no mirroring needed)
+    PairArgs c = base;
+    c.sym = 0; c.mirror = 0; c.swap = 0;
+    const int BT = tile_edge(ctx);
+    int rc;
+    if (Lb < n) {
+        c.i_begin = ra; c.i_end = i_full; c.j_begin = Lb; c.j_end = n;
+        if ((rc = launch_region(ctx, c, BT, ctx->stream, false))) return rc;
+    }
+    if (i_full < re) {
+        c.i_begin = i_full; c.i_end = re; c.j_begin = 0; c.j_end = n;
+        if ((rc = launch_region(ctx, c, BT, ctx->stream, false))) return rc;
+    }
     return HSD_OK;
 }
 
@@ -3096,6 +3239,11 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
                 ok = hipStreamCreateWithFlags(&ctx->side[t], hipStreamNonBlocking) == hipSuccess &&
                      hipEventCreateWithFlags(&ctx->ev_join[t], hipEventDisableTiming) == hipSuccess;
             if (!ok) return hsd_fail(ctx, HSD_ERR_HIP, "side streams: %s", hipGetErrorString(hipGetLastError()));
+        }
+        if (ra > 0 || re < n) {
+            bool done = false;
+            if ((rc = launch_rowblock(ctx, b, ra, re, &done))) return rc;
+            if (done) return HSD_OK;
         }
         if (fork) {
             // the granule lists of the three regions are built on the context's stream BEFORE the fork, so that a side stream

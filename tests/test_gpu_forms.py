@@ -256,3 +256,36 @@ def test_persistent_kernel_row_block_off_the_granule_grid(engine, r0, r1):
         d[r] = np.inf
         order = np.lexsort((np.arange(g.n_node), d))[:9]
         assert np.array_equal(order, idx[r - r0]) and np.array_equal(d[order], val[r - r0])
+
+
+@pytest.mark.parametrize("variant", ["B", "A"])
+def test_row_block_as_one_launch(engine, variant):
+    """A multi-GPU rank's row block [r0, r1) x [0, n) of a Wasserstein matrix runs as ONE persistent launch (diagonal square above its diagonal
+    with per-tile mirror flags + both rectangles, one column-side granule list of three ranges) instead of three launches side by side
+    (HSD_ROWBLOCK=0).  Blocks in the middle, at the top and at the bottom of the matrix, with a partial last row tile and a graph whose size
+    is not a multiple of 128 (column strip), sorted and natural granule order: both forms equal the rows of the full matrix bit for bit, and
+    every entry of the block is written (the block is pre-filled with NaN)."""
+    g = _scale_free(6000 + 55, seed=9)
+    n = g.n_node
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    mode = (0, 1, 0, 2) if variant == "B" else (0, 0, 0, 3)
+    with _Env(HSD_STREAM=0):
+        engine.pair_prepare(*mode)
+        D = engine.pair_rows_host()
+    assert np.array_equal(D, D.T)
+    blocks = [(1280, 2816), (0, 1536), (4608, n), (2560, 2560 + 128 * 5 + 77)]
+    for sort in ("1", "0"):
+        for form in ("1", "0"):
+            with _Env(HSD_STREAM=1, HSD_GRAN_SORT=sort, HSD_ROWBLOCK=form):
+                engine.pair_prepare(*mode)
+                for r0, r1 in blocks:
+                    M = engine.upload_matrix(np.full((r1 - r0, (n + 15) // 16 * 16), np.nan))
+                    M.row0 = r0
+                    M.cols = n
+                    try:
+                        engine.pair_rows_device(r0, r1, M)
+                        got = M.to_host()
+                    finally:
+                        M.free()
+                    assert np.array_equal(got[:, :n], D[r0:r1]), (variant, sort, form, r0, r1, np.nanmax(np.abs(got[:, :n] - D[r0:r1])), int(np.isnan(got[:, :n]).sum()))
