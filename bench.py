@@ -384,7 +384,9 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
     eng.set_graph(g.rowptr, g.col)
     eng.sync()
     t_graph = time.perf_counter() - t0
-    r0, r1 = hdist.init_comm(eng, rk.dist, rk.rank, rk.world) if rk.world > 1 else (0, n)
+    # (a communicator that cannot be made -- a node without working RCCL -- must not lose the run: the counts then travel through the
+    # host, outside the timed region either way, and the line says so under phases_s.exchange)
+    r0, r1 = hdist.init_comm(eng, rk.dist, rk.rank, rk.world, host_fallback=True) if rk.world > 1 else (0, n)
     assert (r0, r1) == hdist.shard_rows(n, rk.world, rk.rank)
     eng.sync()
     t0 = time.perf_counter()
@@ -478,7 +480,10 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
         mat.free()
         out[variant] = res
     return dict(variants=out, sweep=sweep, n_bins=n_bins, rows=(r0, r1),
-                phases=dict(set_graph=round(t_graph, 4), khop_signature_build=round(t_sig, 4), allgather=round(t_gather, 4)))
+                phases=dict(set_graph=round(t_graph, 4), khop_signature_build=round(t_sig, 4), allgather=round(t_gather, 4),
+                            exchange=("none (one GPU)" if rk.world == 1 else
+                                      "ncclAllGather (RCCL)" if getattr(eng, "exchange", "rccl") == "rccl" and not dryrun else
+                                      "host (gloo): " + (getattr(eng, "exchange_reason", "") or "HSD_COMM_DRYRUN rehearsal"))))
 
 
 def cpu_entry(c, variant, hop, what):

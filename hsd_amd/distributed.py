@@ -27,14 +27,41 @@ def shard_rows(n, world, rank):
     return a, min(n, a + rpr)
 
 
-def init_comm(engine, dist, rank, world):
-    """Create the RCCL communicator: rank 0 makes the 128-byte id, `dist` carries it."""
+def init_comm(engine, dist, rank, world, host_fallback=False):
+    """Create the RCCL communicator: rank 0 makes the 128-byte id, `dist` carries it.
+
+    host_fallback=True: if ncclCommInitRank fails on ANY rank (the ranks agree through `dist`), every rank commits the same row
+    partition without a communicator instead of raising, and `engine.exchange` says "host": allgather_signature then moves the counts
+    through host memory (gloo).  The distance kernels do not care how the counts arrived."""
+    import os
     import torch
     idt = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         idt = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).clone()
     dist.broadcast(idt, 0)
-    engine.comm_init(world, rank, bytes(idt.numpy().tobytes()))
+    err = None
+    try:
+        engine.comm_init(world, rank, bytes(idt.numpy().tobytes()))
+    except Exception as e:      # noqa: BLE001  (HsdError: ncclCommInitRank failed)
+        if not host_fallback:
+            raise
+        err = e
+    engine.exchange = "rccl"
+    if host_fallback:
+        bad = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad[0]):
+            old = os.environ.get("HSD_COMM_DRYRUN")
+            os.environ["HSD_COMM_DRYRUN"] = "1"                 # partition without a communicator (csrc/comm.hip)
+            try:
+                engine.comm_init(world, rank, None)
+            finally:
+                if old is None:
+                    os.environ.pop("HSD_COMM_DRYRUN", None)
+                else:
+                    os.environ["HSD_COMM_DRYRUN"] = old
+            engine.exchange = "host"
+            engine.exchange_reason = str(err) if err is not None else "ncclCommInitRank failed on another rank"
     return engine.comm_shard()
 
 
@@ -42,7 +69,7 @@ def allgather_signature(engine, dist=None, rank=0, world=1, via="rccl"):
     """Make every rank hold the counts of all N nodes."""
     if world == 1:
         return
-    if via == "rccl":
+    if via == "rccl" and getattr(engine, "exchange", "rccl") == "rccl":
         engine.signature_allgather()
         return
     # host path: counts of the own block -> gloo all_gather -> upload the other blocks

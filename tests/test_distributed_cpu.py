@@ -15,7 +15,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.environ["HSD_REPO"])
 import torch.distributed as dist
-from hsd_amd.distributed import shard_rows, allgather_signature
+from hsd_amd.distributed import shard_rows, allgather_signature, init_comm
 from hsd_amd.graph import erdos_renyi
 from oracle import hsd_oracle as orc
 from oracle import c_oracle as corc
@@ -36,15 +36,33 @@ class OracleEngine:
     def signature_counts(self, r0, r1): return self.counts[r0:r1].copy()
     def signature_set_counts(self, r0, r1, c): self.counts[r0:r1] = c
     def rows(self, r0, r1): return corc.pair_rows_kl(self.counts, 0, self.hop, 0.5, True, r0, r1)
+    # the communicator calls of hsd_amd.Engine: ncclCommInitRank "fails" on the last rank only (HSD_TEST_COMM_FAIL=1); without a
+    # communicator (the HSD_COMM_DRYRUN form init_comm falls back to) the partition is committed all the same
+    def comm_unique_id(self): return bytes(128)
+    def comm_init(self, world, rank, uid):
+        self.comm_calls = getattr(self, "comm_calls", 0) + 1
+        if os.environ.get("HSD_TEST_COMM_FAIL") and not os.environ.get("HSD_COMM_DRYRUN") and rank == world - 1:
+            raise RuntimeError("RCCL error: ncclCommInitRank: unhandled system error (test)")
+        self.world, self.rank, self.has_comm = world, rank, not os.environ.get("HSD_COMM_DRYRUN")
+    def comm_shard(self): return shard_rows(self.n, self.world, self.rank)
+    def signature_allgather(self): raise AssertionError("the RCCL all-gather must not be reached after a failed communicator")
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 g = erdos_renyi(301, 0.03, seed=9)
 eng = OracleEngine(g, 2)
-r0, r1 = shard_rows(g.n_node, world, rank)
+if os.environ.get("HSD_TEST_COMM_FAIL"):
+    # bench.py's path: init_comm with the host fallback -- every rank must agree on it although only one rank's init failed
+    r0, r1 = init_comm(eng, dist, rank, world, host_fallback=True)
+    assert (r0, r1) == shard_rows(g.n_node, world, rank) and eng.exchange == "host" and not eng.has_comm and eng.comm_calls == 2
+    assert "ncclCommInitRank" in eng.exchange_reason
+    via = "rccl"                                   # what bench.py asks for; the engine's state redirects it
+else:
+    r0, r1 = shard_rows(g.n_node, world, rank)
+    via = "host"
 eng.build(r0, r1)
 assert eng.counts[:r0].sum() == 0 and eng.counts[r1:].sum() == 0
-allgather_signature(eng, dist, rank, world, via="host")
+allgather_signature(eng, dist, rank, world, via=via)
 block = eng.rows(r0, r1)
 np.save(os.path.join(os.environ["HSD_OUT"], f"block_{rank}.npy"), block)
 np.save(os.path.join(os.environ["HSD_OUT"], f"counts_{rank}.npy"), eng.counts)
@@ -65,8 +83,8 @@ def test_shard_rows_cover_everything():
             assert all(a % 128 == 0 for a, b in blocks if b > a)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_block_partition_gloo(tmp_path, world):
+@pytest.mark.parametrize("world,comm_fail", [(2, False), (3, False), (2, True)])
+def test_row_block_partition_gloo(tmp_path, world, comm_fail):
     from hsd_amd.graph import erdos_renyi
     from oracle import hsd_oracle as orc
     from oracle import c_oracle as corc
@@ -76,7 +94,7 @@ def test_row_block_partition_gloo(tmp_path, world):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSD_REPO=REPO, HSD_OUT=str(tmp_path))
+                   HSD_REPO=REPO, HSD_OUT=str(tmp_path), **({"HSD_TEST_COMM_FAIL": "1"} if comm_fail else {}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=300)
