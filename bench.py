@@ -440,15 +440,18 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
             eng.sync()
             t_prep = time.perf_counter() - t0
             cols, ebytes = eng.pair_operand_dims()
+            # this rank's rows of THIS distance: contiguous row blocks of equal planned cost (hsd_pair_shard; the sweep's blocks above
+            # have equal heights) -- the rank that holds a scale-free graph's hub rows would otherwise be ~15 % behind the others
+            p0, p1 = eng.pair_shard(rk.world, rk.rank) if rk.world > 1 else (0, n)
             t0 = time.perf_counter()
-            mat = eng.pair_rows_device(r0, r1)          # allocates this rank's row block (80 GB at N = 100k) and fills it
+            mat = eng.pair_rows_device(p0, p1)          # allocates this rank's row block (80 GB at N = 100k) and fills it
             eng.sync()
             t_first = time.perf_counter() - t0
             # a second prepare + matrix into the existing block: what one more distance matrix costs once the
             # context is warm (buffers, code objects, tile lists exist)
             t0 = time.perf_counter()
             eng.pair_prepare(metric_code, align, lo, hi, 0.5, False)
-            eng.pair_rows_device(r0, r1, mat)
+            eng.pair_rows_device(p0, p1, mat)
             eng.sync()
             t_warm = time.perf_counter() - t0
         except ValueError as e:             # Variant A raises on an empty ring, as scipy does
@@ -459,18 +462,18 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
                 mat.free()
             out[variant] = dict(variant=variant, error=str(err) if err else "Distribution can't be empty. (raised on another rank)")
             continue
-        wall, ev_ms = time_pair(eng, mat, r0, r1, steps, warmup, rk.barrier)
+        wall, ev_ms = time_pair(eng, mat, p0, p1, steps, warmup, rk.barrier)
         work = eng.pair_work()                          # of the last launch
         res = dict(work=work, variant=variant, wall=rk.max(wall), wall_rank=wall, ev_ms=ev_ms, cols=cols, ebytes=ebytes, align=align, lo=lo, hi=hi,
-                   t_prep=t_prep, t_first=t_first, t_warm=t_warm, rows=(r0, r1))
+                   t_prep=t_prep, t_first=t_first, t_warm=t_warm, rows=(p0, p1))
         key = f"{traffic_prefix}_{variant}" if traffic_prefix and rk.world == 1 else None
-        res["roofline"] = kernel_roofline(n, r1 - r0, res, steps, metric, key)
+        res["roofline"] = kernel_roofline(n, p1 - p0, res, steps, metric, key)
         res["pairs_per_s"] = n * (n - 1) / 2.0 * steps / res["wall"]
         res["ms_per_step"] = res["wall"] * 1e3 / steps
         res["dtype"] = dtype_of(res, n_bins)
         res["kernel_ms_per_rank"] = [round(v, 4) for v in rk.gather(ev_ms / steps)]
         if cpu and variant in cpu:
-            res["parity"] = parity_against(mat, r0, cpu[variant]["sample"])
+            res["parity"] = parity_against(mat, p0, cpu[variant]["sample"])
         st = mat.stats()
         res["matrix_check"] = {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")}
         if rk.world == 1 and metric == "wasserstein":
@@ -817,7 +820,7 @@ def main():
         r4 = run_degree_workload(eng, rk, g4, spec4, ["B", "A"], max(3, min(args.steps, 10)), 2, dryrun=dryrun)
         if rank == 0:
             configs.append(dict(config="configs[3]", workload=spec4["name"], nodes=g4.n_node, edges=g4.n_edge, hop=3, bins=r4["n_bins"],
-                                n_gpus=world, rows_of_rank0=list(r4["rows"]), scaling="row blocks over all ranks",
+                                n_gpus=world, rows_of_rank0=list(r4["variants"]["B"].get("rows", r4["rows"])), scaling="row blocks over all ranks (equal planned cost per rank)",
                                 variants=[dict(variant_summary(r4["variants"][v]), kernel_ms_per_rank=r4["variants"][v].get("kernel_ms_per_rank"))
                                           for v in ("B", "A")],
                                 other_kernels=[r4["sweep"]], phases_s=r4["phases"]))
@@ -837,7 +840,8 @@ def main():
             "config": {"workload": f"{spec['name']}, degree-histogram signatures, variant {primary_v} ({variant_call(primary_v) if wass else 'KL on alpha-smoothed ring histograms'}; "
                                    f"layers {prim['lo']}..{prim['hi']}), full symmetric fp64 matrix resident in HBM",
                        "nodes": n, "edges": g.n_edge, "hop": spec["hop"], "bins": r["n_bins"],
-                       "parallelism": f"row-block x{world}", "rows_of_rank0": list(r["rows"])},
+                       "parallelism": f"row-block x{world}" + (" (contiguous blocks of equal planned cost, hsd_pair_shard)" if world > 1 else ""),
+                       "rows_of_rank0": list(prim["rows"])},
             "roofline": prim["roofline"],
             "cpu_baseline": cpu_entry(cpu[primary_v], primary_v, spec["hop"], "the same matrix") if cpu else None,
             "cpu_baseline_pool": dict(value=round(cpu_pool["rate"], 1), unit="node-pairs/s", cores=cpu_pool["workers"], kind="port",

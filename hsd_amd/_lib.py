@@ -73,6 +73,7 @@ SIGNATURES = {
     "hsd_pair_prepare": (_int, [_p, _int, _int, _int, _int, C.c_double, _int]),
     "hsd_pair_rows": (_int, [_p, _i64, _i64, _p, _i64, _int]),
     "hsd_pair_topk": (_int, [_p, _int, _i64, _i64, _p, _p]),
+    "hsd_pair_shard": (_int, [_p, _int, _int, C.POINTER(_i64), C.POINTER(_i64)]),
     "hsd_pair_operand_dims": (_int, [_p, C.POINTER(_int), C.POINTER(_int)]),
     "hsd_pair_work": (_int, [_p, C.POINTER(C.c_double)]),
     "hsd_set_laplacian": (_int, [_p, _i64, _p, _p, _p]),

@@ -741,36 +741,46 @@ __device__ inline void wait_vm_young(int young) {
 // Lane l < n_seg holds segment l.  RI / RJ: most members above the segment's threshold among the nodes of the tile's two
 // sides.  Chooses bin form or (min form) rank form, appends the segment's chunks to the tile's list like plan_segment and
 // leaves in smeta[l] the suffix row to add and the side it belongs to (bit 30: the J side), or -1.
-template <int CH, bool PACK>
-__device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t RI, uint32_t RJ, int l, int2 *lst, int *smeta) {
-    int col0 = sd.bin_col0, words = active ? sd.bin_words : 0, sm = -1, k16 = 1 << 20;
+// The form a tile pair reads a layer segment in (shared by the kernel's planner and by the host's cost estimate of a row partition):
+// first column, words, suffix row | side << 30 (or -1), leading uint16 words.
+struct SegChoice { int col0, words, sm, k16; };
+template <bool PACK>
+__host__ __device__ inline SegChoice choose_segment_form(const HsdSegDesc &sd, bool active, uint32_t RI, uint32_t RJ) {
+    SegChoice c{sd.bin_col0, active ? sd.bin_words : 0, -1, 1 << 20};
     // (bit 31 of a side's maximum: one of its nodes holds a value >= 256 where the uint8 range has bytes)
     const bool wide = ((RI | RJ) >> 31) != 0;
     RI &= 0x7fffffffu; RJ &= 0x7fffffffu;
     if (active && sd.rank_col0 >= 0 && sd.suf_row0 >= 0) {
-        const uint32_t Rm = min(RI, RJ);
+        const uint32_t Rm = RI < RJ ? RI : RJ;
         int wr = PACK ? (int)((Rm + 1) >> 1) : (int)Rm;
         if (sd.rank_low + wr == 0 && sd.rank_cap >= 1) wr = 1;      // a layer always closes with a fold (the longer side's suffix is added there)
         if (wr <= sd.rank_cap) {
-            col0 = sd.rank_col0;
-            words = sd.rank_low + wr;
-            sm = (sd.suf_row0 + wr) | (RI >= RJ ? 0 : (1 << 30));
+            c.col0 = sd.rank_col0;
+            c.words = sd.rank_low + wr;
+            c.sm = (sd.suf_row0 + wr) | (RI >= RJ ? 0 : (1 << 30));
             if (PACK && sd.r8_col0 >= 0 && !wide) {
                 // uint8 range: the rank words beyond the first r8_r16 two-into-one.  The columns end with the uint16 range's
                 // (zeros beyond its cap), so the suffix row is capped there too.
                 const int over = wr - sd.r8_r16, wr8 = over > 0 ? (over + 1) >> 1 : 0, w8 = sd.r8_fixed + wr8;
-                if (wr8 <= sd.r8_cap && w8 >= 1 && w8 < words) {
-                    col0 = sd.r8_col0;
-                    words = w8;
-                    k16 = sd.r8_k16;
-                    sm = (sd.suf_row0 + min(sd.r8_r16 + 2 * wr8, sd.rank_cap)) | (RI >= RJ ? 0 : (1 << 30));
+                if (wr8 <= sd.r8_cap && w8 >= 1 && w8 < c.words) {
+                    const int srow = sd.r8_r16 + 2 * wr8;
+                    c.col0 = sd.r8_col0;
+                    c.words = w8;
+                    c.k16 = sd.r8_k16;
+                    c.sm = (sd.suf_row0 + (srow < sd.rank_cap ? srow : sd.rank_cap)) | (RI >= RJ ? 0 : (1 << 30));
                 }
             }
         }
     }
-    if (l < 4) smeta[l] = sm;
-    const int nch = (words + CH - 1) / CH;
-    return emit_chunks<CH>(nch, col0, words, l, lst, k16);
+    return c;
+}
+
+template <int CH, bool PACK>
+__device__ inline int plan_segment_min(const SegDesc &sd, bool active, uint32_t RI, uint32_t RJ, int l, int2 *lst, int *smeta) {
+    const SegChoice c = choose_segment_form<PACK>(sd, active, RI, RJ);
+    if (l < 4) smeta[l] = c.sm;
+    const int nch = (c.words + CH - 1) / CH;
+    return emit_chunks<CH>(nch, c.col0, c.words, l, lst, c.k16);
 }
 
 // TOPK: the fused k-nearest consumer's instance -- a tile's values below their row's threshold are appended to that row's
@@ -3189,6 +3199,81 @@ extern "C" int hsd_pair_work(hsd_ctx *ctx, double *column_pairs) try {
     HSD_HIP(ctx, hipMemcpyAsync(&w, ctx->d_work, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *column_pairs = (double)w;
+    return HSD_OK;
+} HSD_ABI_GUARD(ctx)
+
+// Row blocks of EQUAL PLANNED COST for `world` ranks (boundaries on whole 128-node tiles): rank g's rows of the prepared distance.
+// The zero-pad kinds read min(R_I, R_J) rank words per tile pair, so a block of hub rows (the first rows of a preferential-attachment
+// graph) costs more per row than a block of leaves: with equal heights the first of 8 ranks took 3.27 ms where the others took 2.8 - 2.95
+// (BA N = 100k, tools_dev/strong_share.py).  Cost of a row tile = sum over the column tiles of (words the planner would read + 32): the
+// 32 stand for what a tile pair costs besides its operand words (folds, stores, hand-over), fitted on those per-rank times.  Kinds whose
+// tiles all cost the same (raw fp64 W1, KL) get equal blocks.  Every rank computes the same partition from the same resident data.
+extern "C" int hsd_pair_shard(hsd_ctx *ctx, int world, int rank, int64_t *r0, int64_t *r1) try {
+    HSD_CHECK_CTX(ctx);
+    if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
+    if (world < 1 || rank < 0 || rank >= world || !r0 || !r1) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_pair_shard: bad world / rank %d / %d", world, rank);
+    const int64_t n = ctx->n, T = (n + 127) / 128;
+    std::vector<double> cost((size_t)T, 1.0);
+    const bool seg = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->d_rmax16 && ctx->n_seg > 0 && ctx->n_seg <= 4 && ctx->ngran16 > 0;
+    const char *eb = getenv("HSD_SHARD_BALANCE");          // 0: equal heights whatever the kind (A/B measurements)
+    const bool balanced = seg && world > 1 && !(eb && atoi(eb) == 0);
+    if (balanced) {
+        const int S = ctx->n_seg, G = ctx->ngran16;
+        std::vector<uint32_t> rm((size_t)S * G);
+        HSD_HIP(ctx, hipMemcpyAsync(rm.data(), ctx->d_rmax16, rm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const auto tile_max = [&](int s, const int32_t *gl, int cnt) {
+            uint32_t m = 0, wide = 0;
+            for (int e = 0; e < cnt; ++e) { const uint32_t v = rm[(size_t)s * G + gl[e]]; m = std::max(m, v & 0x7fffffffu); wide |= v & 0x80000000u; }
+            return m | wide;
+        };
+        // row side: natural tiles (a block's own composition is chosen after the partition); column side: the tiles of the whole graph
+        // in the order the plan chose -- what counts is the distribution of their maxima
+        std::vector<uint32_t> RI((size_t)S * T), RJ;
+        std::vector<int32_t> nat(8);
+        for (int64_t t = 0; t < T; ++t) {
+            int cnt = 0;
+            for (int e = 0; e < 8; ++e) if (8 * t + e < G) nat[(size_t)cnt++] = (int32_t)(8 * t + e);
+            for (int s = 0; s < S; ++s) RI[(size_t)s * T + t] = tile_max(s, nat.data(), cnt);
+        }
+        int64_t TJ = T;
+        const char *es = getenv("HSD_GRAN_SORT");
+        if (!ctx->gran_order.empty() && !(es && atoi(es) == 0)) {
+            TJ = (int64_t)ctx->gran_order.size() / 8;
+            RJ.resize((size_t)S * TJ);
+            for (int64_t t = 0; t < TJ; ++t)
+                for (int s = 0; s < S; ++s) RJ[(size_t)s * TJ + t] = tile_max(s, ctx->gran_order.data() + 8 * t, 8);
+        } else RJ = RI;
+        const bool pack = ctx->mode == PAIR_SAD_U16;
+        for (int64_t t = 0; t < T; ++t) {
+            double c = 0.0;
+            for (int64_t u = 0; u < TJ; ++u) {
+                int w = 32;
+                for (int s = 0; s < S; ++s) {
+                    const uint32_t a = RI[(size_t)s * T + t], b = RJ[(size_t)s * TJ + u];
+                    w += pack ? choose_segment_form<true>(ctx->seg_tab[s], true, a, b).words : choose_segment_form<false>(ctx->seg_tab[s], true, a, b).words;
+                }
+                c += w;
+            }
+            const int64_t rows = std::min<int64_t>(128, n - 128 * t);
+            cost[(size_t)t] = c * (double)rows / 128.0;
+        }
+    } else cost[(size_t)T - 1] *= (double)(n - 128 * (T - 1)) / 128.0;
+    std::vector<double> pre((size_t)T + 1, 0.0);
+    for (int64_t t = 0; t < T; ++t) pre[(size_t)t + 1] = pre[(size_t)t] + cost[(size_t)t];
+    const auto boundary = [&](int g) -> int64_t {           // first tile of rank g
+        if (g <= 0) return 0;
+        if (g >= world) return T;
+        const double want = pre[(size_t)T] * (double)g / (double)world;
+        int64_t b = std::lower_bound(pre.begin(), pre.end(), want) - pre.begin();
+        // (the tile boundary nearest to the target)
+        if (b > 0 && want - pre[(size_t)b - 1] < pre[(size_t)std::min<int64_t>(b, T)] - want) --b;
+        return std::min<int64_t>(std::max<int64_t>(b, 0), T);
+    };
+    int64_t a = boundary(rank), b = boundary(rank + 1);
+    if (b < a) b = a;
+    *r0 = std::min(n, a * 128);
+    *r1 = std::min(n, b * 128);
     return HSD_OK;
 } HSD_ABI_GUARD(ctx)
 

@@ -92,9 +92,10 @@ def allgather_signature(engine, dist=None, rank=0, world=1, via="rccl"):
 
 
 def distance_row_block(engine, metric, align, layer_lo, layer_hi, rank, world, kl_alpha=0.5, device_out=True):
-    """This rank's rows of the distance matrix (DeviceMatrix or numpy), after the exchange."""
-    r0, r1 = shard_rows(engine.n, world, rank)
+    """This rank's rows of the distance matrix (DeviceMatrix or numpy), after the exchange: contiguous row blocks of equal planned
+    cost (hsd_pair_shard), which tile [0, n) in rank order."""
     engine.pair_prepare(metric, align, layer_lo, layer_hi, kl_alpha, False)
+    r0, r1 = engine.pair_shard(world, rank)
     if device_out:
         return engine.pair_rows_device(r0, r1)
     return engine.pair_rows_host(r0, r1)

@@ -260,6 +260,12 @@ class Engine:
     def pair_prepare(self, metric, align, layer_lo, layer_hi, kl_alpha=0.5, kl_sorted=False):
         self._call("hsd_pair_prepare", metric, align, layer_lo, layer_hi, C.c_double(kl_alpha), int(bool(kl_sorted)))
 
+    def pair_shard(self, world, rank):
+        """Rows [r0, r1) of rank `rank` when `world` ranks share the prepared distance in row blocks of equal planned cost."""
+        a, b = C.c_int64(), C.c_int64()
+        self._call("hsd_pair_shard", int(world), int(rank), C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def pair_operand_dims(self):
         a, b = C.c_int(), C.c_int()
         self._call("hsd_pair_operand_dims", C.byref(a), C.byref(b))

@@ -156,6 +156,11 @@ int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, int64_t ld,
  * ascending, ties by smaller index -- without writing the N^2 matrix.  Symmetric distances only
  * (wasserstein, symmetric_kl).  idx_out / dist_out: host, (r1-r0) * k. */
 int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out);
+/* Multi-GPU: rank's rows [*r0, *r1) of the PREPARED distance when `world` ranks share the matrix in contiguous row blocks of equal
+ * planned cost (boundaries on whole 128-row tiles; every rank computes the same partition).  Equal heights -- hsd_comm_shard, the
+ * partition of the sweep -- leave the rank that holds a scale-free graph's hub rows ~15 % behind the others; the blocks still tile
+ * [0, n) in rank order, as the Pool's rows do (model/HSD.py:120-130). */
+int hsd_pair_shard(hsd_ctx *ctx, int world, int rank, int64_t *r0, int64_t *r1);
 /* algorithmic size of the prepared operands: columns per node and bytes per element */
 int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element);
 /* Work of the last hsd_pair_rows call: operand columns (words) x node pairs the kernel evaluated, counted by the

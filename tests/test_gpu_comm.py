@@ -113,3 +113,35 @@ def test_two_ranks_run_the_hip_row_block_path(tmp_path, engine):
                     assert np.array_equal(idx, order) and np.array_equal(val, np.take_along_axis(Dm, order, 1))
     finally:
         os.environ.pop("HSD_STREAM", None)
+
+
+@pytest.mark.gpu
+def test_pair_shard_tiles_the_matrix_and_favours_hub_rows(engine):
+    """hsd_pair_shard: contiguous row blocks of equal PLANNED cost, boundaries on whole 128-row tiles, covering [0, n) in rank order.  On a
+    preferential-attachment graph the first rank (the hubs' rows: more rank words per tile pair under the zero-pad distance) gets fewer rows
+    than the last; the raw fp64 distance (every tile costs the same) gets equal blocks; HSD_SHARD_BALANCE=0 switches the weighting off."""
+    import os
+    from hsd_amd.graph import barabasi_albert
+    g = barabasi_albert(30000 + 50, 5, 42)
+    n = g.n_node
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 1, 0, 2)
+    for world in (1, 2, 3, 8):
+        blocks = [engine.pair_shard(world, r) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        for (a, b), (c, d) in zip(blocks, blocks[1:]):
+            assert b == c and a <= b and b % 128 == 0
+    heights = [b - a for a, b in blocks]
+    assert heights[0] < heights[-1] and heights[0] < n / 8 < max(heights), heights
+    os.environ["HSD_SHARD_BALANCE"] = "0"
+    try:
+        flat = [engine.pair_shard(8, r) for r in range(8)]
+    finally:
+        os.environ.pop("HSD_SHARD_BALANCE", None)
+    assert max(b - a for a, b in flat) - min(b - a for a, b in flat) <= 128 + 50
+    engine.pair_prepare(0, 0, 0, 3)
+    eq = [engine.pair_shard(8, r) for r in range(8)]
+    assert max(b - a for a, b in eq) - min(b - a for a, b in eq) <= 128 + 50
+    with pytest.raises(ValueError):
+        engine.pair_shard(4, 4)

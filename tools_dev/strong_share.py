@@ -21,10 +21,11 @@ for name in variants:
     eng.pair_prepare(*mode)
     reps = 10 if name == "B" else 2
     res = {}
+    balanced = os.environ.get("SHARE_BALANCED", "1") != "0"     # hsd_pair_shard's blocks (equal planned cost) or equal heights
     for P in [1] + plist:
         rows = []
         for r in range(P):
-            r0, r1 = shard_rows(n, P, r) if P > 1 else (0, n)
+            r0, r1 = (eng.pair_shard(P, r) if balanced else shard_rows(n, P, r)) if P > 1 else (0, n)
             M = DeviceMatrix(eng, r1 - r0, n, ld, r0)
             eng.pair_rows_device(r0, r1, M)
             eng.pair_rows_device(r0, r1, M)
