@@ -53,8 +53,9 @@ assert (r0, r1) == hdist.shard_rows(g.n_node, world, rank) == eng.comm_shard()
 eng.signature_build_degree(3, r0, r1)                      # this rank's sources only
 hdist.allgather_signature(eng, dist, rank, world, via="host")
 for name, mode in (("B", (0, 1, 0, 2)), ("A", (0, 0, 0, 3)), ("KL", (1, 0, 0, 3))):
-    blk = hdist.distance_row_block(eng, *mode, rank, world, device_out=False)
+    blk = hdist.distance_row_block(eng, *mode, rank, world, device_out=False)     # rows: hsd_pair_shard (blocks of equal planned cost)
     np.save(os.path.join(os.environ["HSD_OUT"], f"{name}_{rank}.npy"), blk)
+    np.save(os.path.join(os.environ["HSD_OUT"], f"{name}_rows_{rank}.npy"), np.array(eng.pair_shard(world, rank)))
     idx, val = eng.pair_topk(9, r0, r1) if name != "KL" else (None, None)
     if idx is not None:
         np.save(os.path.join(os.environ["HSD_OUT"], f"{name}_topk_{rank}.npy"), np.concatenate([idx.astype(np.float64), val], axis=1))
@@ -94,8 +95,10 @@ def test_two_ranks_run_the_hip_row_block_path(tmp_path, engine):
         for name, mode in (("B", (0, 1, 0, 2)), ("A", (0, 0, 0, 3)), ("KL", (1, 0, 0, 3))):
             engine.pair_prepare(*mode)
             D = engine.pair_rows_host()
+            spans = [tuple(int(v) for v in np.load(tmp_path / f"{name}_rows_{rank}.npy")) for rank in range(2)]
+            assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == n and spans[0][1] % 128 == 0, spans
             for rank in range(2):
-                r0, r1 = shard_rows(n, 2, rank)
+                r0, r1 = spans[rank]
                 blk = np.load(tmp_path / f"{name}_{rank}.npy")
                 assert blk.shape == (r1 - r0, n)
                 if name == "KL":
@@ -105,6 +108,7 @@ def test_two_ranks_run_the_hip_row_block_path(tmp_path, engine):
                     assert np.allclose(blk[:, r0:r1][iu], D[r0:r1, r0:r1][iu], rtol=1e-9, atol=1e-12)
                 else:
                     assert np.array_equal(blk, D[r0:r1]), (name, rank)
+                    r0, r1 = shard_rows(n, 2, rank)                    # (the k-nearest rows were asked for the sweep's block)
                     tk = np.load(tmp_path / f"{name}_topk_{rank}.npy")
                     idx, val = tk[:, :9].astype(np.int64), tk[:, 9:]
                     Dm = D[r0:r1].copy()
