@@ -60,7 +60,7 @@ extern "C" int hsd_comm_init(hsd_ctx *ctx, int world, int rank, const void *id12
     // HSD_COMM_DRYRUN: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks: the row
     // partition is set, no communicator is made (hsd_signature_allgather then fails; the caller exchanges
     // through the host)
-    const bool want_comm = !(world == 1 && !(id128 && getenv("HSD_FORCE_COMM"))) && !getenv("HSD_COMM_DRYRUN");
+    const bool want_comm = !(world == 1 && !(id128 && hsd_hook(H_FORCE_COMM))) && !hsd_hook(H_COMM_DRYRUN);
     if (want_comm) {
         if (!id128) return hsd_fail(ctx, HSD_ERR_INVALID, "null unique id");
         ncclUniqueId id;

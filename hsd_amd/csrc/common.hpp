@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/hsd.h"
+#include "hooks.hpp"
 
 struct ncclComm;
 

@@ -17,6 +17,47 @@ int hsd_fail(hsd_ctx *ctx, int status, const char *fmt, ...) {
     return status;
 }
 
+
+// ---- the environment hooks (csrc/hooks.hpp) ----
+const HsdHookInfo hsd_hook_table[H_COUNT] = {
+    {"HSD_FORCE_COMM", "1 = a one-rank RCCL communicator (single-GPU test of the real all-gather)"},
+    {"HSD_COMM_DRYRUN", "multi-rank control flow without a communicator (the caller exchanges through the host)"},
+    {"HSD_CHEBY_LONGROWS", "heat path: 0 = no chunking of hub rows of the Laplacian"},
+    {"HSD_CHEBY_STORE", "multi-scale heat path: 0 = fused per-step accumulators instead of stored planes"},
+    {"HSD_CHEBY_C", "heat path: cap of the impulse block width"},
+    {"HSD_HEAT_SORT_LDS", "coefficient-sample path: LDS length classes of the ring sort"},
+    {"HSD_HEAT_TILED", "coefficient-sample kernels: 0 = per-pair fallback kernels"},
+    {"HSD_HEAT_GROUPS", "coefficient-sample kernels: column groups per tile"},
+    {"HSD_HEAT_TT", "coefficient-sample kernels: 0 = streamed-slot instead of tile x tile schedule"},
+    {"HSD_HEAT_BCAP", "coefficient-sample kernels: shrunken LDS capacity of the column-side samples (tests)"},
+    {"HSD_HEAT_ACAP", "coefficient-sample kernels: shrunken LDS capacity of the row-side samples (tests)"},
+    {"HSD_HEAT_ROWLDS", "coefficient-sample path (Variant B as written): LDS row cache switch"},
+    {"HSD_KHOP_MS", "0 | 1 = histogram build by the per-source sweep / by the bit-parallel sweep whatever the graph size"},
+    {"HSD_KHOP_BOTTOMUP", "0 | 1 = force the bottom-up expansion of the per-source k-hop sweep off / on"},
+    {"HSD_KHOP_MS_NOPLANES", "test hook: rehearses the allocation failure of the bit-parallel sweep's planes"},
+    {"HSD_TILE", "one-tile pair kernel with that tile edge (64 | 128); also keeps the persistent kernel off"},
+    {"HSD_SUPERTILE", "tile-order group size S (S x S tiles per group, default 8; 1 = formula order)"},
+    {"HSD_XCD_DEAL", "0 = tile groups in row-major order instead of dealt round-robin to the XCDs"},
+    {"HSD_PLAN_VERBOSE", "hsd_pair_prepare prints the chosen order, thresholds, byte ranges and stage times to stderr"},
+    {"HSD_WAVES_PER_CU", "resident waves of the persistent kernel per CU (default 8)"},
+    {"HSD_STREAM", "pair kernel: 0 = one tile per workgroup for every tile, 1 = force the persistent kernel also for small regions"},
+    {"HSD_GRAN_SORT", "0 = tiles composed in natural granule order instead of the planner's sorted order"},
+    {"HSD_ROWBLOCK", "0 = a row block as three launches (square + two rectangles) instead of one persistent launch"},
+    {"HSD_SAD16", "0 = zero-pad W1 on plain uint32 columns; read at prepare time"},
+    {"HSD_RANK", "zero-pad layers: 0 = bin form only, 1 = whole-layer rank form only, 2 = thresholds (default); read at prepare time"},
+    {"HSD_PLAN_THREADS", "cap of the host threads that price the candidate granule orders (1 = the calling thread only)"},
+    {"HSD_PLAN_THREADS_FAIL", "test hook: creating the t-th planning thread fails (what RLIMIT_NPROC does)"},
+    {"HSD_U8", "0 = packed zero-pad layers without their uint8 ranges; read at prepare time"},
+    {"HSD_SHARD_BALANCE", "0 = hsd_pair_shard returns blocks of equal height whatever the kind"},
+    {"HSD_DEBUG", "ablation bits of the pair kernels: 1 no stores, 2 no arithmetic, 16 stores stay in L2; 4 / 8 only in -DHSD_STAMPS builds"},
+    {"HSD_SIDE_STREAMS", "0 = the three regions of a row block in sequence instead of side by side (three-launch form only)"},
+    {"HSD_TOPK_DEBUG", "fused k-nearest consumer: 1 = sweep without its candidate epilogue (timing only: the call then fails)"},
+    {"HSD_TOPK_PHASES", "fused k-nearest consumer: number of equal phases of the sweep"},
+    {"HSD_TOPK_GEOM", "fused k-nearest consumer: 0 | 1 = never / always the geometric launch schedule"},
+    {"HSD_TOPK_CAP", "fused k-nearest consumer: capacity of a row's candidate list (overflow -> retry path)"},
+    {"HSD_TOPK_VERBOSE", "fused k-nearest consumer: per-attempt list statistics to stderr"},
+};
+
 int hsd_guard_status(hsd_ctx *ctx, int status, const char *what) noexcept {
     if (ctx) {
         try { ctx->err = what; } catch (...) { ctx->err.clear(); }      // (the assignment itself may need memory)
@@ -65,6 +106,13 @@ extern "C" int hsd_create(int device, hsd_ctx **out) try {
         hipMemset(ctx->d_work, 0, sizeof(unsigned long long)) != hipSuccess) {
         hsd_destroy(ctx);          // releases whatever was created (all members start null)
         return HSD_ERR_HIP;
+    }
+    if (const char *el = getenv("HSD_HOOKS_LIST")) {
+        if (atoi(el) != 0)
+            for (int h = 0; h < H_COUNT; ++h) {
+                const char *v = hsd_hook((HsdHook)h);
+                fprintf(stderr, "[hsd hook] %-22s %-8s %s\n", hsd_hook_table[h].name, v ? v : "-", hsd_hook_table[h].doc);
+            }
     }
     *out = ctx;
     return HSD_OK;

@@ -512,7 +512,7 @@ extern "C" int hsd_set_laplacian(hsd_ctx *ctx, int64_t n, const int64_t *rowptr,
     ctx->lpartial_cols = 0;
     std::vector<int32_t> row_first((size_t)n, -1), chunk_row;
     std::vector<int64_t> chunk_p0;
-    const char *el = getenv("HSD_CHEBY_LONGROWS");
+    const char *el = hsd_hook(H_CHEBY_LONGROWS);
     if (!(el && atoi(el) == 0))
         for (int64_t i = 0; i < n; ++i) {
             const int64_t len = rowptr[i + 1] - rowptr[i];
@@ -746,10 +746,10 @@ extern "C" int hsd_multiscale_ring_stats(hsd_ctx *ctx, int hop, const double *co
     const int64_t budget = (int64_t)std::min<size_t>(free_b / 2, (size_t)48 << 30);
     int64_t C_store = (budget / ((int64_t)(order + 1 + SP) * n * (int64_t)sizeof(double))) / 32 * 32;
     bool store = C_store >= 64;
-    if (const char *es = getenv("HSD_CHEBY_STORE")) store = store && atoi(es) != 0;
+    if (const char *es = hsd_hook(H_CHEBY_STORE)) store = store && atoi(es) != 0;
     int64_t C = store ? std::min<int64_t>(512, C_store)
                       : std::max<int64_t>(32, std::min<int64_t>(512, (((int64_t)4 << 30) / ((3 + SP) * n * (int64_t)sizeof(double))) / 32 * 32));
-    if (const char *ec = getenv("HSD_CHEBY_C")) C = std::max<int64_t>(32, std::min<int64_t>(C, atoll(ec) / 32 * 32));   // measurement hook
+    if (const char *ec = hsd_hook(H_CHEBY_C)) C = std::max<int64_t>(32, std::min<int64_t>(C, atoll(ec) / 32 * 32));   // measurement hook
     C = std::min<int64_t>(C, (nsrc + 31) / 32 * 32);
     const int n_planes = store ? order + 1 : 3;
     double *Tall = nullptr, *R = nullptr, *d_sums = nullptr, *d_coef = nullptr;
@@ -846,7 +846,7 @@ extern "C" int hsd_heat_signature_build(hsd_ctx *ctx, int hop, const double *psi
     const size_t cap = ctx->prop.maxSharedMemoryPerMultiProcessor ? ctx->prop.maxSharedMemoryPerMultiProcessor : 65536;
     int64_t lds_max_len = 1;
     while (lds_max_len * 2 * (int64_t)sizeof(double) <= (int64_t)cap) lds_max_len <<= 1;
-    const char *eg = getenv("HSD_HEAT_SORT_LDS");       // test hook: smaller LDS classes
+    const char *eg = hsd_hook(H_HEAT_SORT_LDS);       // test hook: smaller LDS classes
     if (eg && atoll(eg) >= 2) lds_max_len = std::min<int64_t>(lds_max_len, atoll(eg));
     const int64_t small_len = std::min<int64_t>(2048, lds_max_len);
     std::vector<int64_t> cls[3];
@@ -935,7 +935,7 @@ extern "C" int hsd_pair_heat_rows(hsd_ctx *ctx, int layer_lo, int layer_hi, int6
     if (layer_lo < 0 || layer_hi > ctx->heat_hop || layer_lo > layer_hi) return hsd_fail(ctx, HSD_ERR_INVALID, "bad layer range");
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
     // rank-axis tiled kernel (heatpair.hip); HSD_HEAT_TILED=0 keeps the value-axis merge, one thread per pair
-    const char *et = getenv("HSD_HEAT_TILED");
+    const char *et = hsd_hook(H_HEAT_TILED);
     rc = (et && atoi(et) == 0) ? HSD_ERR_UNSUPPORTED : hsd_launch_pair_ragged_tiled(ctx, layer_lo, layer_hi, r0, r1, dst, dld);
     if (rc != HSD_OK && rc != HSD_ERR_UNSUPPORTED) return rc;
     for (int64_t ra = r0; rc == HSD_ERR_UNSUPPORTED && ra < r1; ra += 32768) {       // gridDim.y limit
@@ -962,7 +962,7 @@ extern "C" int hsd_pair_heat_rowform(hsd_ctx *ctx, const double *psi_dev, int64_
     if (rc) return rc;
     // one row of psi per workgroup, one partner per wave (heatpair.hip); HSD_HEAT_TILED=0 or rings too large
     // for a wave slot: one workgroup per pair
-    const char *et = getenv("HSD_HEAT_TILED");
+    const char *et = hsd_hook(H_HEAT_TILED);
     rc = (et && atoi(et) == 0) ? HSD_ERR_UNSUPPORTED : hsd_launch_pair_rowquirk_tiled(ctx, psi_dev, ldpsi, r0, r1, dst, dld);
     if (rc != HSD_OK && rc != HSD_ERR_UNSUPPORTED) return rc;
     if (rc == HSD_ERR_UNSUPPORTED) {

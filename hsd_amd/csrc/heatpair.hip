@@ -764,7 +764,7 @@ static int launch_pair_ragged_tt(hsd_ctx *ctx, int layer_lo, int layer_hi, int64
         // an even count the light and the heavy workgroups would each land on their own half of the XCDs
         // (measured: 2 groups 79 ms, 1 or 3 groups 54 ms at ER N=10k)
         int groups = std::max(1, (1024 + rows_tiles - 1) / std::max(rows_tiles, 1));
-        if (const char *eg = getenv("HSD_HEAT_GROUPS")) groups = std::max(1, atoi(eg));      // measurement hook
+        if (const char *eg = hsd_hook(H_HEAT_GROUPS)) groups = std::max(1, atoi(eg));      // measurement hook
         groups = std::min(groups, std::max(1, n_tiles / 4));
         groups |= 1;
         const size_t lds = (size_t)2 * cap * sizeof(double) + aux;
@@ -791,8 +791,8 @@ static int launch_pair_ragged_tt(hsd_ctx *ctx, int layer_lo, int layer_hi, int64
 int hsd_launch_pair_ragged_tiled(hsd_ctx *ctx, int layer_lo, int layer_hi, int64_t r0, int64_t r1, double *dst, int64_t dld) {
     {
         // both sides resident (16 waves per CU) when every sample fits half the LDS; HSD_HEAT_TT=0: streamed slots
-        const char *ett = getenv("HSD_HEAT_TT");
-        if (!(ett && atoi(ett) == 0) && !getenv("HSD_HEAT_BCAP") && !getenv("HSD_HEAT_ACAP")) {
+        const char *ett = hsd_hook(H_HEAT_TT);
+        if (!(ett && atoi(ett) == 0) && !hsd_hook(H_HEAT_BCAP) && !hsd_hook(H_HEAT_ACAP)) {
             const int rtt = launch_pair_ragged_tt(ctx, layer_lo, layer_hi, r0, r1, dst, dld);
             if (rtt != HSD_ERR_UNSUPPORTED) return rtt;
         }
@@ -811,10 +811,10 @@ int hsd_launch_pair_ragged_tiled(hsd_ctx *ctx, int layer_lo, int layer_hi, int64
     if (aux + 4096 > lds_max) return HSD_ERR_UNSUPPORTED;
     const int64_t budget = (int64_t)((lds_max - aux - 64) / sizeof(double));
     int64_t b_cap = std::min<int64_t>({max_span + 2, budget * 5 / 8 / RG_WAVES, (int64_t)64 * RG_SLOT_REGS});
-    if (const char *e = getenv("HSD_HEAT_BCAP")) b_cap = std::min<int64_t>(b_cap, atoll(e));
+    if (const char *e = hsd_hook(H_HEAT_BCAP)) b_cap = std::min<int64_t>(b_cap, atoll(e));
     b_cap = std::max<int64_t>(b_cap, 3);
     int64_t a_cap = budget - b_cap * RG_WAVES;
-    if (const char *e = getenv("HSD_HEAT_ACAP")) a_cap = std::max<int64_t>(3, std::min<int64_t>(a_cap, atoll(e)));   // test hook
+    if (const char *e = hsd_hook(H_HEAT_ACAP)) a_cap = std::max<int64_t>(3, std::min<int64_t>(a_cap, atoll(e)));   // test hook
     // resident tiles: consecutive nodes packed while they fit
     std::vector<int32_t> tiles;
     tiles.push_back((int32_t)r0);
@@ -874,7 +874,7 @@ int hsd_launch_pair_rowquirk_tiled(hsd_ctx *ctx, const double *psi_dev, int64_t 
     const size_t base = (size_t)p_cap * sizeof(double) + aux + (size_t)RQ_WAVES * id_cap * sizeof(int32_t);
     if (base > lds_max) return HSD_ERR_UNSUPPORTED;
     int row_in_lds = base + (size_t)n * sizeof(double) <= lds_max ? 1 : 0;
-    if (const char *er = getenv("HSD_HEAT_ROWLDS")) if (atoi(er) == 0) row_in_lds = 0;      // measurement hook
+    if (const char *er = hsd_hook(H_HEAT_ROWLDS)) if (atoi(er) == 0) row_in_lds = 0;      // measurement hook
     const size_t lds = base + (row_in_lds ? (size_t)n * sizeof(double) : 0);
     const int groups = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + r1 - 1) / r1, n / (2 * RQ_WAVES) + 1)) | 1;   // odd, as above
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pair_rowquirk_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -176,7 +176,7 @@ int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, in
     // 3 n x 512 B of planes + 2 (hop - 1) n x 512 B of ring planes: if they cannot be allocated (a large graph next to its
     // own [n][hop + 1][bins] histogram tensor) the per-source sweep below, which needs LDS bitmaps only, takes over.
     const auto ms_wanted = [&]() {
-        if (const char *em = getenv("HSD_KHOP_MS")) return atoi(em) != 0;
+        if (const char *em = hsd_hook(H_KHOP_MS)) return atoi(em) != 0;
         return n >= 8192 && hop >= 2 && r1 - r0 >= 2048;
     };
     if (!hist && d_sizes && !d_members && r1 > r0 && ms_wanted()) {
@@ -203,7 +203,7 @@ int hsd_launch_khop(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, bool hist, in
     // The frontier bitmap of the bottom-up expansion costs LDS, i.e. resident workgroups per CU: it is taken
     // for deep sweeps (hop >= 4: the last hops cover most of a small-world graph) and whenever it is free.
     const size_t lds2 = ((size_t)2 * words + n_hist + 8) * sizeof(uint32_t), lds3 = lds2 + (size_t)words * sizeof(uint32_t);
-    const char *eb = getenv("HSD_KHOP_BOTTOMUP");        // 0 / 1 force it off / on
+    const char *eb = hsd_hook(H_KHOP_BOTTOMUP);        // 0 / 1 force it off / on
     bool bottom_up = lds3 <= lds_cap && (hop >= 4 || std::min<size_t>(8, lds_cap / lds3) == std::min<size_t>(8, lds_cap / std::max<size_t>(lds2, 1)));
     if (eb) bottom_up = atoi(eb) != 0 && lds3 <= lds_cap;
     const size_t lds_bytes = bottom_up ? lds3 : lds2;

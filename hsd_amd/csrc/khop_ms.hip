@@ -311,7 +311,7 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, uint32_t *
         ctx->ms_plane_words = 0;
         // (no room for the planes: the caller falls back to the per-source sweep, which needs LDS bitmaps only;
         // HSD_KHOP_MS_NOPLANES=1 rehearses that in the tests)
-        if (getenv("HSD_KHOP_MS_NOPLANES")) return HSD_INT_NO_PLANES;
+        if (hsd_hook(H_KHOP_MS_NOPLANES)) return HSD_INT_NO_PLANES;
         if (hipMalloc(reinterpret_cast<void **>(&ctx->d_ms_planes), words * sizeof(*ctx->d_ms_planes)) != hipSuccess) {
             ctx->d_ms_planes = nullptr;
             (void)hipGetLastError();

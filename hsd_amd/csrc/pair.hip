@@ -1851,7 +1851,7 @@ int tile_edge(const hsd_ctx *ctx) {
     // arithmetic dominates; the short uint32 kernels at small column counts are bound by the store
     // stream and prefer many small independent workgroups (measured in DESIGN.md).  HSD_TILE overrides.
     if (ctx->mode == PAIR_ZP_F64) return 64;      // fallback kind is built for 64 x 64 only
-    const char *e = getenv("HSD_TILE");
+    const char *e = hsd_hook(H_TILE);
     if (e) return atoi(e) == 128 ? 128 : 64;
     if ((ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16) && ctx->seg_begin[ctx->n_seg] <= 128) return 64;   // padded bin-form words
     return 128;
@@ -1871,10 +1871,10 @@ int tile_edge(const hsd_ctx *ctx) {
 // k-nearest consumer tightens its thresholds between such phases).
 const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls, bool part_i, bool part_j, int *count, int phase = 0,
                        int n_phases = 1, int phase_w = 1) {
-    const char *e = getenv("HSD_SUPERTILE");
+    const char *e = hsd_hook(H_SUPERTILE);
     const int S = e ? atoi(e) : 8;
     if (S <= 1 && cls == 0 && n_phases <= 1) { if (count) *count = -1; return nullptr; }
-    const char *ed = getenv("HSD_XCD_DEAL");
+    const char *ed = hsd_hook(H_XCD_DEAL);
     const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
     if (n_phases < 1) n_phases = 1;
     if (phase_w < 1) phase_w = 1;
@@ -1942,7 +1942,7 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
                        (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t) + (TOPK ? 512 : 0);
     // (two workgroups per CU need 2 x lds <= 160 KiB: the integer kinds with three per-node vectors sit ~300 bytes below that -- at 96
     // bytes above it, after the segment descriptions had grown, the k-nearest sweep of BA N = 200k ran at half occupancy: 105 vs 66 ms)
-    if (getenv("HSD_PLAN_VERBOSE") && 2 * lds > (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor)
+    if (hsd_hook(H_PLAN_VERBOSE) && 2 * lds > (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor)
         fprintf(stderr, "[hsd stream<%d,%d,%d>] %zu bytes of LDS per workgroup: ONE workgroup per CU\n", KIND, NW, (int)TOPK, lds);
     // the attribute is per device: remembered per context (one context per GPU), not per process
     size_t &attr_lds = ctx->lds_attr[reinterpret_cast<const void *>(kern)];
@@ -1953,7 +1953,7 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     }
     // persistent grid: two waves per SIMD on every CU (HSD_WAVES_PER_CU overrides), a multiple of 8 so that every XCD
     // gets the same number of workgroups; a workgroup with no tile in its XCD's run exits at once
-    const char *ew = getenv("HSD_WAVES_PER_CU");
+    const char *ew = hsd_hook(H_WAVES_PER_CU);
     const int per_cu = ew ? std::max(NW, atoi(ew)) : 8;
     const int64_t resident = (int64_t)(per_cu / NW) * ctx->prop.multiProcessorCount / 8 * 8;
     const int grid = (int)std::min<int64_t>(resident, round_up(a.ntiles, 8));
@@ -2001,8 +2001,8 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
 // fused k-nearest consumer runs its own instantiation (TOPK).  HSD_STREAM=0 or an explicit HSD_TILE: the
 // one-tile-per-workgroup kernel for every tile (A/B measurements; the tests run both and compare them bit for bit).
 int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
-    if (const char *ew = getenv("HSD_STREAM")) if (atoi(ew) == 0) return 0;
-    if (getenv("HSD_TILE")) return 0;
+    if (const char *ew = hsd_hook(H_STREAM)) if (atoi(ew) == 0) return 0;
+    if (hsd_hook(H_TILE)) return 0;
     if (ctx->mode == PAIR_ZP_F64) return 0;
     const bool aligned = (a.i_begin % 16 == 0) && (a.j_begin % 16 == 0) && (a.npad % 4 == 0) &&
                          (a.tau || ((a.ld % 2 == 0) && a.ld < (int64_t)30000000 && (reinterpret_cast<uintptr_t>(a.out) % 16 == 0)));
@@ -2015,7 +2015,7 @@ int stream_waves(const hsd_ctx *ctx, const PairArgs &a) {
     // (tools_dev/xover.py, end of round 3: the integer kinds cross over at ~11 tiles per workgroup -- zero-pad, BA N = 14k: 0.385 one-tile /
     // 0.358 persistent, N = 16k: 0.500 / 0.376 -- the fp64 kinds within 3 % of each other between 12 and 16 tiles)
     const int64_t per_wg = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) ? 11 : 16;
-    const char *ew = getenv("HSD_STREAM");
+    const char *ew = hsd_hook(H_STREAM);
     if (!(ew && atoi(ew) != 0) && tiles < per_wg * 2 * (int64_t)ctx->prop.multiProcessorCount) return 0;
     return 4;
 }
@@ -2066,7 +2066,7 @@ __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, i
 // hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank segments.  Cached per
 // context until the operands are released; false if it cannot be built.
 bool gran_list_ranges(hsd_ctx *ctx, const int64_t (&r)[6], hipStream_t stream, hsd_ctx::GranList *out) {
-    const char *es = getenv("HSD_GRAN_SORT");
+    const char *es = hsd_hook(H_GRAN_SORT);
     const int sorted = (!ctx->gran_order.empty() && !(es && atoi(es) == 0)) ? 1 : 0;      // (the two orders of a range are cached side by side)
     for (size_t k = 0; k < ctx->gran_lists.size(); ++k) {
         const auto &c = ctx->gran_lists[k];
@@ -2232,7 +2232,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
         }
         // (a list could not be built: fall through to the one-tile kernel over every tile)
     }
-    if (BT == 128 && !getenv("HSD_TILE") && ctx->mode != PAIR_ZP_F64) {
+    if (BT == 128 && !hsd_hook(H_TILE) && ctx->mode != PAIR_ZP_F64) {
         // few tiles per CU: the small tile's five workgroups per CU overlap their phases better than two large ones
         // (ER N = 10k, raw fp64 W1: 0.321 ms with 64 x 64 tiles against 0.351 ms with 128 x 128)
         const int64_t t128i = (a.i_end - a.i_begin + 127) / 128, t128j = (a.j_end - a.j_begin + 127) / 128;
@@ -2261,9 +2261,9 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
 // square, the rectangle right of it.  Of the square only the tiles on or above its diagonal are listed, those above it flagged
 // (TILE_MIRROR_FLAG in the row index) to be written mirrored as well; the rest as tile_order does: S x S groups dealt round-robin to the XCDs.
 const int2 *rowblock_tile_order(hsd_ctx *ctx, int nI, int nA, int nB, int *count) {
-    const char *e = getenv("HSD_SUPERTILE");
+    const char *e = hsd_hook(H_SUPERTILE);
     const int G = std::max(e ? atoi(e) : 8, 1);
-    const char *ed = getenv("HSD_XCD_DEAL");
+    const char *ed = hsd_hook(H_XCD_DEAL);
     const int deal = (ed && atoi(ed) == 0) ? 0 : 1;
     const int nJ = nA + nI + nB;
     const int sym_key = 2 | (nA << 2), key = (G & 0xff) | (deal << 25);
@@ -2328,7 +2328,7 @@ int launch_rowblock(hsd_ctx *ctx, const PairArgs &base, int64_t ra, int64_t re, 
     *done = false;
     const int64_t n = ctx->n;
     const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
-    { const char *e = getenv("HSD_ROWBLOCK"); if (e && atoi(e) == 0) return HSD_OK; }       // A/B and tests: the three-launch form
+    { const char *e = hsd_hook(H_ROWBLOCK); if (e && atoi(e) == 0) return HSD_OK; }       // A/B and tests: the three-launch form
     if (!wass || ra % 128 != 0 || (ra == 0 && re == n)) return HSD_OK;
     const int n_aux = ctx->n_seg + (base.point ? 1 : 0);
     if (n_aux > 3) return HSD_OK;
@@ -2643,7 +2643,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     const int B = p.B;
     int rc;
     // HSD_PLAN_VERBOSE: wall time of the stages (synchronising: measurement only)
-    const bool vt = getenv("HSD_PLAN_VERBOSE") != nullptr;
+    const bool vt = hsd_hook(H_PLAN_VERBOSE) != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
         if (!vt) return;
@@ -2714,7 +2714,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         mark("column maxima");
         // uint16 packing: two columns per word, one v_sad_u16 covers both.  A column whose values (tail count x bin
         // width) reach 65536 is split into columns of smaller width (|T_i - T_j| (d1 + d2) is the sum of both parts).
-        const char *e16 = getenv("HSD_SAD16");
+        const char *e16 = hsd_hook(H_SAD16);
         bool pack = !(e16 && atoi(e16) == 0);
         std::vector<int> vsrc;
         std::vector<uint32_t> vdiv, vmul;
@@ -2745,7 +2745,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         //   low words + E[ rank words if they fit the cap, else the upper bin words ]
         // over all granule pairs (exact from the sorted maxima); the cheapest candidate is stored, or none if nothing
         // beats the plain bin form by 3 %.
-        const char *er = getenv("HSD_RANK");
+        const char *er = hsd_hook(H_RANK);
         const int rank_mode = er ? atoi(er) : 2;                // 0: bin form only; 1: theta = 0 only; 2: any threshold
         bool rank_ok = rank_mode != 0;
         if (pack && ctx->support.back() >= 65536.0) rank_ok = false;      // member values must fit a uint16 half
@@ -2808,7 +2808,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         double best_total = (double)nl_hist * bin_words;
         bool best_sorted = false;
         if (rank_ok && bin_words >= 2 && G16 >= 1) {
-            const char *es = getenv("HSD_GRAN_SORT");
+            const char *es = hsd_hook(H_GRAN_SORT);
             const bool may_sort = !(es && atoi(es) == 0) && G16 >= 16;
             const int64_t NT = std::max<int64_t>(1, G16 / 8);     // tiles of eight granules (a last, shorter group counts as one)
             std::vector<int32_t> order((size_t)G16);
@@ -2862,7 +2862,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                 std::vector<std::vector<int32_t>> t_order((size_t)n_task);
                 std::vector<std::vector<LayerPlan>> t_plan((size_t)n_task, std::vector<LayerPlan>((size_t)nl_hist));
                 std::vector<double> t_total((size_t)n_task, 0.0);
-                const char *ept = getenv("HSD_PLAN_THREADS");    // cap of the host threads (1: everything on the calling thread)
+                const char *ept = hsd_hook(H_PLAN_THREADS);    // cap of the host threads (1: everything on the calling thread)
                 int thr_cap = ept ? atoi(ept) : 16;
                 if (thr_cap < 1) thr_cap = 1;
                 const int n_thr = std::max(1, std::min<int>(std::min(n_task, thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
@@ -2885,7 +2885,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                     std::vector<std::thread> pool;
                     try {
                         pool.reserve((size_t)n_thr);
-                        const char *eft = getenv("HSD_PLAN_THREADS_FAIL");       // test hook: creating the t-th thread fails
+                        const char *eft = hsd_hook(H_PLAN_THREADS_FAIL);       // test hook: creating the t-th thread fails
                         const int fail_at = eft ? atoi(eft) : 0;
                         for (int t = 1; t < n_thr; ++t) {
                             if (t == fail_at) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
@@ -2908,7 +2908,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         ctx->gran_order.clear();
         if (best_sorted) ctx->gran_order = best_order;
         int suf_rows = 1;                                         // row 0: zeros
-        const char *e8 = getenv("HSD_U8");
+        const char *e8 = hsd_hook(H_U8);
         const bool u8_ok = !(e8 && atoi(e8) == 0);               // HSD_U8=0: no uint8 ranges (tests: same bits either way)
         std::vector<int> r8_reserved((size_t)nl_hist, -1);
         for (int sgi = 0; sgi < nl_hist; ++sgi) {
@@ -2936,7 +2936,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax, rmax_sel.data(), rmax_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax16, rmax16_sel.data(), rmax16_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // rmax_sel / rmax16_sel are locals
-        if (getenv("HSD_PLAN_VERBOSE")) {
+        if (hsd_hook(H_PLAN_VERBOSE)) {
             fprintf(stderr, "[hsd plan] %s granule order, expected words per tile pair %.1f (bin form %d per layer):", best_sorted ? "sorted" : "natural", best_total,
                     bin_words);
             for (int sgi = 0; sgi < nl_hist; ++sgi)
@@ -3076,7 +3076,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                 if ((int)gb8[g] > best_b || (int)gr8[g] > best_r) gR[g] |= 0x80000000u;
             HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax16 + (size_t)sgi * ngran16, gR, (size_t)ngran16 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // gR (rmax16_sel) / temporaries
-            if (getenv("HSD_PLAN_VERBOSE"))
+            if (hsd_hook(H_PLAN_VERBOSE))
                 fprintf(stderr, "[hsd plan] layer %d uint8 range: %d low-bin + %d rank words stay uint16, %d + up to %d words of bytes; saves %.1f words per tile pair\n", sgi,
                         best_b, best_r, nb8, d.r8_cap, best_save);
         }
@@ -3215,7 +3215,7 @@ extern "C" int hsd_pair_shard(hsd_ctx *ctx, int world, int rank, int64_t *r0, in
     const int64_t n = ctx->n, T = (n + 127) / 128;
     std::vector<double> cost((size_t)T, 1.0);
     const bool seg = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->d_rmax16 && ctx->n_seg > 0 && ctx->n_seg <= 4 && ctx->ngran16 > 0;
-    const char *eb = getenv("HSD_SHARD_BALANCE");          // 0: equal heights whatever the kind (A/B measurements)
+    const char *eb = hsd_hook(H_SHARD_BALANCE);          // 0: equal heights whatever the kind (A/B measurements)
     const bool balanced = seg && world > 1 && !(eb && atoi(eb) == 0);
     if (balanced) {
         const int S = ctx->n_seg, G = ctx->ngran16;
@@ -3237,7 +3237,7 @@ extern "C" int hsd_pair_shard(hsd_ctx *ctx, int world, int rank, int64_t *r0, in
             for (int s = 0; s < S; ++s) RI[(size_t)s * T + t] = tile_max(s, nat.data(), cnt);
         }
         int64_t TJ = T;
-        const char *es = getenv("HSD_GRAN_SORT");
+        const char *es = hsd_hook(H_GRAN_SORT);
         if (!ctx->gran_order.empty() && !(es && atoi(es) == 0)) {
             TJ = (int64_t)ctx->gran_order.size() / 8;
             RJ.resize((size_t)S * TJ);
@@ -3301,7 +3301,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
     a.list_cap = ctx->list_cap;
     a.work = ctx->d_work;
     a.hmode = ctx->mode == PAIR_SKL ? 1 : 0;
-    { const char *e = getenv("HSD_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+    { const char *e = hsd_hook(H_DEBUG); a.dbg = e ? atoi(e) : 0; }
     a.dcols_valid = (ctx->mode == PAIR_SKL) ? ctx->dcols : ctx->dcols_alg;
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned long long), ctx->stream));
 
@@ -3316,7 +3316,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
         // The diagonal square (symmetric) and the rectangles left and right of it write disjoint parts of the
         // row block: a multi-GPU rank has all three, and they run side by side (two side streams forked from
         // and joined back into the context's stream) so that their tails overlap.  HSD_SIDE_STREAMS=0: in sequence.
-        const char *es = getenv("HSD_SIDE_STREAMS");
+        const char *es = hsd_hook(H_SIDE_STREAMS);
         bool fork = (ra > 0 || re < n) && !(es && atoi(es) == 0);
         if (fork && !ctx->ev_fork) {
             bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -3427,7 +3427,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     a.list_cap = ctx->list_cap;
     a.work = nullptr;
     a.hmode = ctx->mode == PAIR_SKL ? 1 : 0;
-    { const char *e = getenv("HSD_TOPK_DEBUG"); a.dbg = e ? atoi(e) : 0; }     // measurement: 1 = sweep without its candidate epilogue
+    { const char *e = hsd_hook(H_TOPK_DEBUG); a.dbg = e ? atoi(e) : 0; }     // measurement: 1 = sweep without its candidate epilogue
     a.dcols_valid = (ctx->mode == PAIR_SKL) ? ctx->dcols : ctx->dcols_alg;
     a.rbase = r0;
     a.i_begin = r0; a.i_end = r1;
@@ -3456,15 +3456,15 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
         const int64_t t128 = (rows + 127) / 128, tiles = t128 * ((n + 127) / 128);
         const int cus = std::max(1, ctx->prop.multiProcessorCount);
         while (n_phases < 8 && tiles / (2 * n_phases) >= 64 * (int64_t)cus) n_phases *= 2;
-        if (const char *ep = getenv("HSD_TOPK_PHASES")) n_phases = std::max(1, std::min(16, atoi(ep)));
-        else if (const char *eg = getenv("HSD_TOPK_GEOM")) geometric = atoi(eg) != 0;
+        if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
+        else if (const char *eg = hsd_hook(H_TOPK_GEOM)) geometric = atoi(eg) != 0;
     }
     struct Launch { int lo, w, mod; bool compact_after; };
     std::vector<Launch> sched;
     if (geometric) {
         sched = {{0, 1, 32, true}, {1, 1, 32, false}, {2, 2, 32, false}, {4, 4, 32, true}, {8, 8, 32, true}, {16, 16, 32, false}};
         n_phases = 32;                                // (the list capacity below is sized by the first launch's share)
-    } else if (n_phases == 8 && !getenv("HSD_TOPK_PHASES")) {
+    } else if (n_phases == 8 && !hsd_hook(H_TOPK_PHASES)) {
         // eight equal phases with the FIRST one in two halves and a compaction in between: the sampled thresholds are the loosest
         // the sweep ever uses (a 2 % quantile), and half a phase under them appends 122 instead of 244 entries per row before the
         // first tightening (-10^7 appends at BA N = 100k against 0.42 ms for the extra compaction: 19.5 -> 19.25 ms; N = 200k: 72 -> 66 ms).
@@ -3481,7 +3481,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     // equal distances (the integer zero-pad distances tie by the hundred); an overflow anywhere costs a whole retry
     int64_t cap = std::min<int64_t>(n, n_phases > 1 ? std::max<int64_t>(2048, 8 * (int64_t)k * n / (M * n_phases) + 8 * k + 64)
                                                     : std::max<int64_t>(256, 4 * (int64_t)k * n / M + 64));
-    if (const char *ec = getenv("HSD_TOPK_CAP")) cap = std::min<int64_t>(n, std::max<int64_t>(k + 1, atoll(ec)));   // test hook
+    if (const char *ec = hsd_hook(H_TOPK_CAP)) cap = std::min<int64_t>(n, std::max<int64_t>(k + 1, atoll(ec)));   // test hook
     int rc = HSD_OK;
     for (int attempt = 0; attempt < 3 && rc == HSD_OK; ++attempt) {
         if (attempt == 1) { M = std::min<int64_t>(n, 4 * M); cap = std::min<int64_t>(n, 8 * cap); }
@@ -3558,7 +3558,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = hipGetLastError();
         }
-        if (getenv("HSD_TOPK_VERBOSE") && rc == HSD_OK && e == hipSuccess) {
+        if (hsd_hook(H_TOPK_VERBOSE) && rc == HSD_OK && e == hipSuccess) {
             std::vector<int> hc((size_t)rows);
             (void)hipMemcpy(hc.data(), d_cnt, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost);
             int64_t mx = 0, over = 0;

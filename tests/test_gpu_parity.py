@@ -309,3 +309,64 @@ def test_engine_close_returns_the_hbm_of_live_matrices():
     assert M.ptr is None and len(eng._matrices) == 0
     M.free()                                    # no-op, no call into a destroyed context
     del M
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["single_node", "single_edge", "three_isolated", "complete_20", "path_5_deep_hop", "star_300"])
+def test_degenerate_graphs(engine, kind):
+    """The smallest and most uniform inputs: one node, one edge, no edges at all, a complete graph (every pair tied at 0), a path swept
+    deeper than its diameter (empty outer rings), a star.  Ring sizes against the C oracle; Variant B (zero-pad: defined on empty rings)
+    against the oracle on every pair; Variant A raises like scipy wherever a compared ring is empty and matches otherwise; the k-nearest
+    consumer on the all-ties matrix orders by index."""
+    from oracle import c_oracle as corc
+    from hsd_amd.graph import Graph
+    K = 3
+    if kind == "single_node":
+        n, src, dst = 1, [], []
+    elif kind == "single_edge":
+        n, src, dst = 2, [0], [1]
+    elif kind == "three_isolated":
+        n, src, dst = 3, [], []
+    elif kind == "complete_20":
+        n = 20
+        ii, jj = np.triu_indices(n, 1)
+        src, dst = ii, jj
+    elif kind == "path_5_deep_hop":
+        n, src, dst, K = 5, [0, 1, 2, 3], [1, 2, 3, 4], 6
+    else:
+        n = 300
+        src, dst = np.zeros(n - 1, dtype=np.int64), np.arange(1, n)
+    g = Graph.from_edges(list(range(n)), np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64))
+    engine.set_graph(g.rowptr, g.col)
+    sizes = engine.khop_sizes(K)
+    assert np.array_equal(sizes, corc.khop_sizes(g.rowptr, g.col, K))
+    engine.signature_build_degree(K)
+    rs = corc.RingSamples(g.rowptr, g.col, K, g.degree.astype(np.float64))
+    engine.pair_prepare(0, 1, 0, K - 1)
+    DB = engine.pair_rows_host()
+    RB, _ = rs.pair_rows(0, K - 1, corc.ALIGN_ZEROPAD, 0, n)
+    assert DB.shape == (n, n) and np.allclose(DB, RB, rtol=1e-6, atol=1e-12) and np.array_equal(DB, DB.T)
+    if (sizes == 0).any():
+        with pytest.raises(ValueError, match="Distribution can't be empty."):
+            engine.pair_prepare(0, 0, 0, K)
+    else:
+        engine.pair_prepare(0, 0, 0, K)
+        DA = engine.pair_rows_host()
+        RA, _ = rs.pair_rows(0, K, corc.ALIGN_NONE, 0, n)
+        assert np.allclose(DA, RA, rtol=1e-6, atol=1e-12)
+    if kind == "complete_20":
+        assert not DB.any()
+        engine.pair_prepare(0, 1, 0, K - 1)
+        idx, val = engine.pair_topk(5)
+        for i in range(n):
+            assert list(idx[i]) == [j for j in range(n) if j != i][:5] and not val[i].any()
+    if n >= 2:
+        engine.pair_prepare(0, 1, 0, K - 1)
+        idx, val = engine.pair_topk(1)
+        Dm = DB.copy()
+        np.fill_diagonal(Dm, np.inf)
+        assert np.array_equal(val[:, 0], Dm.min(axis=1))
+    else:
+        with pytest.raises(ValueError):
+            engine.pair_prepare(0, 1, 0, K - 1)
+            engine.pair_topk(1)                       # k must be <= n - 1
