@@ -31,6 +31,42 @@ def test_loader_sets_prototypes_and_version():
     assert lib.hsd_abi_version() == 1
     assert lib.hsd_strerror(-5) == b"Distribution can't be empty."
     assert lib.hsd_strerror(-8) == b"The sum of probability distribution must be 1.0."
+    assert lib.hsd_strerror(_lib.ERR_NOMEM) == b"out of host memory" and b"exception" in lib.hsd_strerror(_lib.ERR_INTERNAL)
+
+
+def test_every_entry_point_stops_exceptions_at_the_boundary():
+    """Every int-returning extern "C" definition of the library is a function-try-block closed by HSD_ABI_GUARD: no C++ exception (bad_alloc
+    from a std::vector, system_error from a thread that cannot be created) reaches a ctypes / cgo / JNI caller as std::terminate."""
+    csrc = os.path.join(REPO, "hsd_amd", "csrc")
+    n_defs = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip"):
+            continue
+        text = open(os.path.join(csrc, f), encoding="utf-8").read()
+        for m in re.finditer(r'^extern "C" int (hsd_[a-z0-9_]+)\(([^;{]*?)\)\s*(try)?\s*\{', text, flags=re.M | re.S):
+            if m.group(1) == "hsd_abi_version":
+                continue
+            n_defs += 1
+            assert m.group(3) == "try", f"{f}: {m.group(1)} is not a function-try-block"
+        assert text.count(") try {") == text.count("} HSD_ABI_GUARD("), f
+    assert n_defs >= 40
+
+
+def test_environment_hooks_are_one_table_and_documented():
+    """csrc/hooks.hpp is the only place the library reads the environment (plus the table printer), and DESIGN.md section 9 names every hook."""
+    csrc = os.path.join(REPO, "hsd_amd", "csrc")
+    hooks = re.findall(r'^\s*H_([A-Z0-9_]+),', open(os.path.join(csrc, "hooks.hpp"), encoding="utf-8").read(), flags=re.M)
+    assert len(hooks) >= 30
+    table = open(os.path.join(csrc, "context.hip"), encoding="utf-8").read()
+    design = open(os.path.join(REPO, "DESIGN.md"), encoding="utf-8").read()
+    for h in hooks:
+        assert f'{{"HSD_{h}"' in table, f"HSD_{h} missing from hsd_hook_table"
+        assert f"HSD_{h}" in design, f"HSD_{h} is not documented in DESIGN.md"
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            text = open(os.path.join(csrc, f), encoding="utf-8").read()
+            stray = [m for m in re.findall(r'getenv\("([A-Z_0-9]+)"\)', text) if m != "HSD_HOOKS_LIST"]
+            assert not stray, (f, stray)
 
 
 def test_no_oracle_import_in_product():
