@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsd_amd
 from hsd_amd.graph import barabasi_albert, erdos_renyi, connect_components
 
-HOOKS = ("HSD_STREAM", "HSD_TILE", "HSD_RANK", "HSD_SAD16", "HSD_XCD_DEAL", "HSD_SUPERTILE", "HSD_GRAN_SORT", "HSD_U8")
+HOOKS = ("HSD_STREAM", "HSD_TILE", "HSD_RANK", "HSD_SAD16", "HSD_XCD_DEAL", "HSD_SUPERTILE", "HSD_GRAN_SORT", "HSD_U8", "HSD_ROWBLOCK")
 
 
 def with_env(env, fn):
@@ -51,7 +51,8 @@ def soak(eng, seed=1, budget_s=120.0, max_blocks=None, n_max=4200):
             if rng.random() < 0.2: env["HSD_SUPERTILE"] = str(int(rng.choice([1, 4, 16])))
             if rng.random() < 0.3: env["HSD_GRAN_SORT"] = "0"
             if rng.random() < 0.2: env["HSD_U8"] = "0"
-            gran = int(rng.choice([1, 2, 4, 16, 64, 128]))
+            if rng.random() < 0.3: env["HSD_ROWBLOCK"] = "0"       # a row block as three launches instead of one
+            gran = int(rng.choice([1, 2, 4, 16, 64, 128, 128, 128]))      # (128: the one-launch row block)
             r0 = int(rng.integers(0, n)) // gran * gran
             r1 = int(rng.integers(r0 + 1, n + 1)) if rng.random() < 0.7 else n
 
