@@ -478,6 +478,8 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
         res["matrix_check"] = {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")}
         if rk.world == 1 and metric == "wasserstein":
             res["fused_knn"] = fused_knn(eng, mat, n, 20)
+            if n >= 50000:
+                res["row_block_rehearsal"] = row_block_rehearsal(eng, mat, n, res["roofline"]["kernel_ms"], heavy=(variant == "A"))
         # (last: it clears the block the checks above read)
         res["roofline"]["fill_same_bytes"] = fill_reference(eng, mat, res["roofline"]["kernel_ms"])
         mat.free()
@@ -519,6 +521,41 @@ def fused_knn(eng, mat, n, k):
                 note="k nearest of every row without forming the matrix; time includes the results' copy to host memory")
 
 
+def row_block_rehearsal(eng, mat, n, kernel_ms, heavy):
+    """What a rank of `bench.py --gpus P` would compute, measured on THIS GPU: for P = 2, 4, 8 every rank's row block of the same matrix
+    (hsd_pair_shard: contiguous blocks of equal planned cost; one persistent launch per block) timed alone, one after the other.  The
+    slowest block is what P identical GPUs would take before any communication or launch skew -- NOT a multi-GPU measurement (the driver's
+    SCALE run is); it is here because a single-GPU box is the only hardware this build ever sees.  Rows 0 and the last row of every block
+    are compared with the resident one-GPU matrix, bit for bit."""
+    from hsd_amd.engine import DeviceMatrix
+    out = {"note": "each rank's row block of the SAME matrix run alone on this one GPU (no communication, no launch skew in it): the time of the "
+                   "slowest block is the floor of `bench.py --gpus P`; not a multi-GPU measurement", "one_gpu_ms": round(kernel_ms, 3), "by_P": {}}
+    ld = (n + 15) // 16 * 16
+    reps = 1 if heavy else 3
+    for P in (2, 4, 8):
+        per, same = [], True
+        for r in range(P):
+            r0, r1 = eng.pair_shard(P, r)
+            if r1 <= r0:
+                per.append(0.0)
+                continue
+            blk = DeviceMatrix(eng, r1 - r0, n, ld, r0)
+            try:
+                eng.pair_rows_device(r0, r1, blk)
+                eng.timer_start()
+                for _ in range(reps):
+                    eng.pair_rows_device(r0, r1, blk)
+                per.append(eng.timer_stop() / reps)
+                for row in (r0, r1 - 1):
+                    same = same and bool(np.array_equal(blk.rows_to_host(row - r0, row - r0 + 1), mat.rows_to_host(row, row + 1)))
+            finally:
+                blk.free()
+        out["by_P"][str(P)] = dict(per_rank_ms=[round(v, 3) for v in per], rows_first_rank=list(eng.pair_shard(P, 0)),
+                                   slowest_ms=round(max(per), 3), speedup_of_slowest_rank=round(kernel_ms / max(per), 2),
+                                   rows_identical_to_one_gpu_matrix=same)
+    return out
+
+
 def variant_summary(res):
     if "error" in res:
         return dict(variant=res["variant"], error=res["error"])
@@ -526,7 +563,7 @@ def variant_summary(res):
                 ms_per_step=res["ms_per_step"], dtype=res["dtype"], roofline=res["roofline"], parity=res.get("parity"),
                 phases_s=dict(operand_prepare_first=round(res["t_prep"], 4), first_matrix_incl_allocation=round(res["t_first"], 4),
                               warm_prepare_plus_matrix=round(res["t_warm"], 4)),
-                matrix_check=res["matrix_check"], fused_knn=res.get("fused_knn"))
+                matrix_check=res["matrix_check"], fused_knn=res.get("fused_knn"), row_block_rehearsal=res.get("row_block_rehearsal"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -857,6 +894,7 @@ def main():
                              end_to_end_one_matrix_warm=round(r["phases"]["khop_signature_build"] + r["phases"]["allgather"] + prim["t_warm"], 4)),
             "matrix_check": prim["matrix_check"],
             "fused_knn": prim.get("fused_knn"),
+            "row_block_rehearsal": prim.get("row_block_rehearsal"),
             "configs": configs,
             "device": info["arch"], "cus": info["compute_units"],
         }
