@@ -167,3 +167,21 @@ def test_triple_and_hierarchical_degree():
         psi = orc.heat_wavelets_exact(L, s)
         for i in range(g.n_node):
             assert np.allclose(orc.get_triple(psi, rings[i], i), T["emb"][i, si], rtol=0, atol=1e-13)
+
+
+def test_weighted_graph_oracle_against_the_reference():
+    """Weighted Laplacian (3-column edgelist lines; 2-column lines weigh 1): the oracle's wavelets and both distance variants against
+    what the reference computed from the same file (tests/golden/generate_golden_weighted.py)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN, load_graph
+    from oracle import hsd_oracle as orc
+    W = np.load(os.path.join(GOLDEN, "weighted.npz"))
+    g = load_graph("karate_weighted")
+    assert np.array_equal(g.laplacian_dense(), W["L"])
+    rings = orc.khop_rings(g.rowptr, g.col, 3)
+    for si, s in enumerate(W["scales"]):
+        psi = orc.heat_wavelets_exact(g.laplacian_dense(), float(s))
+        assert np.allclose(psi, W[f"psi{si}"], rtol=0, atol=1e-13)
+        assert np.allclose(orc.distance_variant_a(orc.hierarchical_coefficients(psi, rings), 3), W[f"A{si}"], rtol=1e-9, atol=1e-13)
+        assert np.allclose(orc.distance_variant_b_rowquirk(psi, rings, 3), W[f"B{si}"], rtol=1e-9, atol=1e-13)
