@@ -20,6 +20,36 @@ def _graph(name):
     return load_graph(name)
 
 
+@pytest.mark.parametrize("name", ["PTC", "citeseer", "usa", "cora"])
+def test_khop_membership_of_the_larger_shipped_graphs(engine, name):
+    """The reference's data files with the awkward line formats (PTC lists every edge twice, citeseer has lines with a third column,
+    ids that do not start at 0): node order as networkx gives it, ring members at K = 2 and ring sizes at K = 3 as
+    tools.get_hierarchical_representation computed them (tests/golden/generate_golden_rings_more.py), bit for bit; the degree histograms
+    of both sweeps (per-source and bit-parallel) are the histograms of those rings."""
+    import os
+    R = np.load(os.path.join(GOLDEN, "rings_more.npz"))
+    g = load_graph(name)
+    assert g.nodes == list(R[f"{name}/nodes"]) and g.n_edge == int(R[f"{name}/n_edges"][0])
+    engine.set_graph(g.rowptr, g.col)
+    off, mem = engine.khop_members(2)
+    assert np.array_equal(off, R[f"{name}/K2/offsets"]) and np.array_equal(mem, R[f"{name}/K2/members"])
+    assert np.array_equal(engine.khop_sizes(3), R[f"{name}/K3/sizes"])
+    support = np.unique(g.degree)
+    binof = np.searchsorted(support, g.degree)
+    for force in ("0", "1"):
+        os.environ["HSD_KHOP_MS"] = force
+        try:
+            engine.signature_build_degree(2)
+        finally:
+            os.environ.pop("HSD_KHOP_MS", None)
+        counts = engine.signature_counts()
+        assert counts.shape == (g.n_node, 3, support.size)
+        for v in (0, g.n_node // 2, g.n_node - 1):
+            for k in range(3):
+                ring = mem[off[v * 3 + k]:off[v * 3 + k + 1]]
+                assert np.array_equal(counts[v, k], np.bincount(binof[ring], minlength=support.size)), (name, force, v, k)
+
+
 @pytest.mark.parametrize("name", ["karate", "barbell", "mkarate", "tree", "robust", "line", "europe"])
 @pytest.mark.parametrize("K", [2, 3, 5])
 def test_khop_membership_bit_exact(engine, name, K):

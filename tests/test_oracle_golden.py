@@ -185,3 +185,24 @@ def test_weighted_graph_oracle_against_the_reference():
         assert np.allclose(psi, W[f"psi{si}"], rtol=0, atol=1e-13)
         assert np.allclose(orc.distance_variant_a(orc.hierarchical_coefficients(psi, rings), 3), W[f"A{si}"], rtol=1e-9, atol=1e-13)
         assert np.allclose(orc.distance_variant_b_rowquirk(psi, rings, 3), W[f"B{si}"], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["PTC", "citeseer", "usa", "cora"])
+def test_rings_of_the_larger_shipped_graphs(name):
+    """Node order, ring members (K = 2) and ring sizes (K = 3) of the reference's larger data files (duplicate edge lines, mixed 2- / 3-column
+    lines, ids not starting at 0) against tools.get_hierarchical_representation (generate_golden_rings_more.py)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN, load_graph
+    from oracle import c_oracle as corc
+    from oracle import hsd_oracle as orc
+    R = np.load(os.path.join(GOLDEN, "rings_more.npz"))
+    g = load_graph(name)
+    assert g.nodes == list(R[f"{name}/nodes"])
+    assert np.array_equal(corc.khop_sizes(g.rowptr, g.col, 3), R[f"{name}/K3/sizes"])
+    off = R[f"{name}/K2/offsets"]
+    mem = R[f"{name}/K2/members"]
+    for v in (0, 1, g.n_node // 2, g.n_node - 1):
+        rings = orc.khop_rings_node(g.rowptr, g.col, v, 2)
+        for k in range(3):
+            assert np.array_equal(np.asarray(rings[k], dtype=np.int32), mem[off[v * 3 + k]:off[v * 3 + k + 1]])
