@@ -289,3 +289,6 @@ def test_row_block_as_one_launch(engine, variant):
                     finally:
                         M.free()
                     assert np.array_equal(got[:, :n], D[r0:r1]), (variant, sort, form, r0, r1, np.nanmax(np.abs(got[:, :n] - D[r0:r1])), int(np.isnan(got[:, :n]).sum()))
+                # the same blocks into host memory (through the staging block: another base pointer, leading dimension and row origin)
+                r0, r1 = blocks[0]
+                assert np.array_equal(engine.pair_rows_host(r0, r1), D[r0:r1]), (variant, sort, form, "host")
