@@ -400,3 +400,49 @@ def test_degenerate_graphs(engine, kind):
         with pytest.raises(ValueError):
             engine.pair_prepare(0, 1, 0, K - 1)
             engine.pair_topk(1)                       # k must be <= n - 1
+
+
+@pytest.mark.gpu
+def test_contexts_return_their_hbm(engine):
+    """Create / use / destroy a context several times (graph, sweep, every distance kind, row blocks, the k-nearest consumer, the heat
+    path, resident matrices left to Engine.close()): the device's free memory afterwards is what it was before (hipMemGetInfo, asked of
+    the HIP runtime directly -- the library has no such entry point)."""
+    import ctypes
+    import hsd_amd
+    from hsd_amd.graph import barabasi_albert
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        engine.sync()
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    g = barabasi_albert(9000 + 33, 5, 3)
+    kar = load_graph("karate")
+
+    def cycle():
+        eng = hsd_amd.Engine(0)
+        eng.set_graph(g.rowptr, g.col)
+        eng.signature_build_degree(3)
+        os.environ["HSD_STREAM"] = "1"
+        try:
+            for mode in ((0, 1, 0, 2), (0, 0, 0, 3), (1, 0, 0, 3), (2, 0, 0, 3)):
+                eng.pair_prepare(*mode)
+                M = eng.pair_rows_device(1280, 4096)          # left alive: close() must return it
+                eng.pair_rows_host(0, 300)
+                if mode[0] != 1:
+                    eng.pair_topk(7, 100, 900)
+        finally:
+            os.environ.pop("HSD_STREAM", None)
+        m = hsd_amd.HSD(kar, "karate", 1.0, 3, "wasserstein", engine=eng)
+        m.calculate_structural_distance(1.0, approx=True)
+        assert M.ptr
+        eng.close()
+
+    cycle()                                       # first cycle: code objects, runtime pools
+    before = free_bytes()
+    for _ in range(3):
+        cycle()
+    after = free_bytes()
+    assert before - after < 32 << 20, (before, after, before - after)
