@@ -1,6 +1,7 @@
 """dev: randomized soak of the bit-parallel sweep against the per-source sweep (counts must be identical).
 usage: python3 tools_dev/fuzz_khop.py [seconds=60] [seed=1]"""
 import os, sys, time
+_tick = [time.time()]
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsd_amd
@@ -33,4 +34,6 @@ while time.time() - t0 < budget:
             print("MISMATCH", dict(kind=int(kind), n=n, hop=hop, r0=r0, r1=r1, bins=None if nb is None else int(nb.max()) + 1), flush=True)
             sys.exit(1)
         cases += 1
+        if time.time() - _tick[0] > 60:      # (a line a minute: a silent run is taken to be hung by the GPU box's watchdog)
+            _tick[0] = time.time(); print(f"... {cases} cases after {time.time() - t0:.0f} s", flush=True)
 print(f"fuzz_khop: {cases} cases identical in {time.time() - t0:.0f} s", flush=True)

@@ -4,6 +4,7 @@ rows of a reference matrix (one-tile kernel, bin form), bit for bit for the Wass
 usage: python3 tools_dev/fuzz_pair.py [seconds=120] [seed=1] [n_max=4200]      (tests/test_gpu_fuzz.py runs one seed inside -m gpu;
 n_max ~12000 brings hubs whose rings exceed a byte: tiles that must not read a layer's uint8 range)"""
 import os, sys, time
+_tick = [time.time()]
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsd_amd
@@ -72,6 +73,8 @@ def soak(eng, seed=1, budget_s=120.0, max_blocks=None, n_max=4200):
                 bad = np.argwhere(got != want)
                 return cases, dict(graph=gdesc, hop=hop, mode=mode, env=env, rows=(r0, r1), first_bad=bad[:3].tolist(), n_bad=len(bad))
             cases += 1
+            if time.time() - _tick[0] > 60:      # (a line a minute: a silent run is taken to be hung by the GPU box's watchdog)
+                _tick[0] = time.time(); print(f"... {cases} cases after {time.time() - t0:.0f} s", flush=True)
     return cases, None
 
 

@@ -2,6 +2,7 @@
 natural tile composition) against a lexicographic selection on the full matrix.
 usage: python3 tools_dev/fuzz_topk.py [seconds=90] [seed=1]      (tests/test_gpu_fuzz.py runs one seed inside -m gpu)"""
 import os, sys, time
+_tick = [time.time()]
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsd_amd
@@ -57,6 +58,8 @@ def soak(eng, seed=1, budget_s=90.0, max_calls=None, n_max=5000):
                 if not (same_val and (same_idx or mode[0] == 2)):
                     return cases, dict(graph=gdesc, hop=hop, mode=mode, k=k, env=env, rows=(a, b), row=int(r))
             cases += 1
+            if time.time() - _tick[0] > 60:      # (a line a minute: a silent run is taken to be hung by the GPU box's watchdog)
+                _tick[0] = time.time(); print(f"... {cases} cases after {time.time() - t0:.0f} s", flush=True)
     return cases, None
 
 

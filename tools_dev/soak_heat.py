@@ -2,6 +2,7 @@
 (thresholded psi, order 50) and MultiHSD.embed (ring [sum, mean] for several scales from one recurrence, both schedules),
 stars and hubs included (long-row chunks).  usage: python3 tools_dev/soak_heat.py [seconds=120] [seed=1]"""
 import os, sys, time
+_tick = [time.time()]
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -54,4 +55,6 @@ while time.time() - t0 < budget:
                 if e2 > 1e-9:
                     print("MISMATCH embed", dict(kind=kind, n=n, seed=seed, sched=sched, scale=float(sc), node=int(i), err=float(e2)), flush=True); sys.exit(1)
     cases += 1
+    if time.time() - _tick[0] > 60:      # (a line a minute: a silent run is taken to be hung by the GPU box's watchdog)
+        _tick[0] = time.time(); print(f"... {cases} cases after {time.time() - t0:.0f} s", flush=True)
 print(f"soak_heat: {cases} graphs, wavelets and multi-scale ring statistics match the oracle (worst abs difference {worst:.2e}) in {time.time() - t0:.0f} s", flush=True)
