@@ -79,7 +79,8 @@ def parse():
                          "B: tools.metrics.calculate_distance zero-pad alignment, layers 0..K-1 (model/HSD.py:140-161)")
     ap.add_argument("--configs", default=None,
                     help="comma list of the other BASELINE configs measured beside the headline (2,3,5 on one GPU; 4: on eight GPUs the "
-                         "row-block matrix, on one GPU the k-nearest consumer only); 'none' to skip.  Default: 2,3,4,5 at --gpus 1, 4 at --gpus 8, none otherwise")
+                         "row-block matrix, on one GPU the k-nearest consumer only; 'extra': the headline kernel on an Erdos-Renyi graph of the target's size); "
+                         "'none' to skip.  Default: 2,3,4,5,extra at --gpus 1, 4 at --gpus 8, none otherwise")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the scipy baseline sample of the headline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--weak", action="store_true", help="round-1 weak-scaling mode: ER N = nodes * sqrt(P), per-GPU output fixed")
@@ -622,6 +623,18 @@ def run_config2(eng, rk, steps, warmup, cpu_seconds):
     return ent
 
 
+def run_extra_er100k(eng, rk, steps, warmup):
+    """NOT a BASELINE configuration: the headline kernel (Variant B) at the target's size on the OTHER graph family -- Erdos-Renyi, mean
+    degree 10, N = 100 000: 24 degree bins instead of 241, ~11 operand words per pair instead of ~51.  It shows what the kernel's store
+    path reaches when the arithmetic beside it is light (tools_dev/size_sweep.py has the whole size / family table)."""
+    spec = dict(graph="er", nodes=100000, p=1e-4, hop=3, metric="wasserstein",
+                name="extra (not a BASELINE config): erdos_renyi N=100000 p=0.0001 seed=42, K=3, Wasserstein, variant B")
+    g = make_graph(spec)
+    r = run_degree_workload(eng, rk, g, spec, ["B"], steps, warmup)
+    return dict(config="extra", workload=spec["name"], nodes=g.n_node, edges=g.n_edge, hop=3, bins=r["n_bins"], steps=steps,
+                variants=[variant_summary(r["variants"]["B"])], other_kernels=[r["sweep"]], phases_s=r["phases"])
+
+
 def run_config3(eng, rk, steps, warmup, cpu_seconds):
     """KL on alpha-smoothed per-ring histograms; CPU baseline = the C restatement of
     tools/metrics.py:74-88 on the same histograms (kind "port": the reference's KL has no runnable semantics on ring
@@ -810,7 +823,7 @@ def main():
 
     cfg_list = args.configs
     if cfg_list is None:
-        cfg_list = "none" if custom or args.workload != "target" else ("2,3,4,5" if world == 1 else ("4" if world == 8 else "none"))
+        cfg_list = "none" if custom or args.workload != "target" else ("2,3,4,5,extra" if world == 1 else ("4" if world == 8 else "none"))
     cfgs = [] if cfg_list == "none" else [c.strip() for c in cfg_list.split(",") if c.strip()]
 
     # ---- CPU baseline first (rank 0, single GPU only): the process pool forks, which must happen
@@ -846,6 +859,8 @@ def main():
                     configs.append(run_config5(eng, min(args.cpu_seconds, 10.0)))
                 elif c == "4":
                     configs.append(run_config4_one_gpu(eng))
+                elif c == "extra":
+                    configs.append(run_extra_er100k(eng, rk, csteps, cwarm))
             except Exception as e:        # noqa: BLE001  (a side configuration must not lose the headline)
                 configs.append(dict(config=c, error=f"{type(e).__name__}: {e}"))
     if world > 1 and "4" in cfgs:
