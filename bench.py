@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--configs", default=None,
                     help="comma list of the other BASELINE configs measured beside the headline (2,3,5 on one GPU; 4: on eight GPUs the "
                          "row-block matrix, on one GPU the k-nearest consumer only; 'extra': the headline kernel on an Erdos-Renyi graph of the target's size); "
-                         "'none' to skip.  Default: 2,3,4,5,extra at --gpus 1, 4 at --gpus 8, none otherwise")
+                         "'none' to skip.  Default: extra,2,3,4,5 at --gpus 1, 4 at --gpus 8, none otherwise")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the scipy baseline sample of the headline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--weak", action="store_true", help="round-1 weak-scaling mode: ER N = nodes * sqrt(P), per-GPU output fixed")
@@ -823,7 +823,7 @@ def main():
 
     cfg_list = args.configs
     if cfg_list is None:
-        cfg_list = "none" if custom or args.workload != "target" else ("2,3,4,5,extra" if world == 1 else ("4" if world == 8 else "none"))
+        cfg_list = "none" if custom or args.workload != "target" else ("extra,2,3,4,5" if world == 1 else ("4" if world == 8 else "none"))
     cfgs = [] if cfg_list == "none" else [c.strip() for c in cfg_list.split(",") if c.strip()]
 
     # ---- CPU baseline first (rank 0, single GPU only): the process pool forks, which must happen

@@ -8,7 +8,7 @@ import hsd_amd
 which = sys.argv[1] if len(sys.argv) > 1 else "B"
 eng = hsd_amd.Engine(0)
 CASES = [("ba", 20000), ("ba", 40000), ("ba", 70000), ("ba", 100000), ("ba", 150000), ("er", 20000), ("er", 50000), ("er", 100000), ("er", 150000)]
-print(f"{'graph':>6} {'n':>7} {'var':>3} {'ms':>9} {'of 8 TB/s':>10} {'words/pair':>11} {'fill ms':>8} {'kernel/fill':>11}", flush=True)
+print(f"{'graph':>6} {'n':>7} {'var':>3} {'best ms':>9} {'mean ms':>9} {'of 8 TB/s (mean)':>17} {'words/pair':>11} {'fill ms (mean)':>15} {'kernel/fill':>11}", flush=True)
 for kind, n in CASES:
     g = hsd_amd.barabasi_albert(n, 5, 42) if kind == "ba" else hsd_amd.erdos_renyi(n, 10.0 / n, 42)
     eng.set_graph(g.rowptr, g.col)
@@ -21,18 +21,18 @@ for kind, n in CASES:
             continue
         M = eng.pair_rows_device()
         eng.pair_rows_device(0, None, M)
-        reps = 5 if v == "B" else 2
+        reps = 10 if v == "B" else 2
         ts = []
         for _ in range(reps):
             eng.timer_start(); eng.pair_rows_device(0, None, M); ts.append(eng.timer_stop())
-        ms = min(ts)
+        ms = sum(ts) / len(ts)
         words = eng.pair_work() / (n * (n - 1) / 2.0)
         cols, eb = eng.pair_operand_dims()
         alg = 8.0 * n * n + float(eb) * n * cols
         fills = []
-        for _ in range(3):
+        for _ in range(5):
             eng.timer_start(); eng._call("hsd_memset", C.c_void_p(M.ptr), 0, C.c_size_t(M.rows * M.ld * 8)); fills.append(eng.timer_stop())
-        fill = min(fills)
+        fill = sum(fills) / len(fills)
         M.free()
-        print(f"{kind:>6} {n:>7} {v:>3} {ms:9.3f} {alg / (ms * 1e-3) / 8e12:10.3f} {words:11.1f} {fill:8.3f} {ms / fill:11.2f}", flush=True)
+        print(f"{kind:>6} {n:>7} {v:>3} {min(ts):9.3f} {ms:9.3f} {alg / (ms * 1e-3) / 8e12:17.3f} {words:11.1f} {fill:15.3f} {ms / fill:11.2f}", flush=True)
 eng.close()
