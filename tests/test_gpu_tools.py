@@ -62,3 +62,34 @@ def test_two_models_share_one_engine(engine):
     assert np.array_equal(m1.parallel_calculate_HSD(), d1)               # m1 again: rebinds, same result
     assert np.array_equal(m2.calculate_wavelets(0.5, approx=False), w2)  # and m2 again
     assert m1.get_nodes_hierarchical_degree()[m1.nodes[0]][0] == 1
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py as the driver runs it (a child process, flags --gpus/--steps/--warmup), on a small custom workload: ONE JSON line on stdout with
+    the contract's keys -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
+    config.workload, the roofline object (bound, achieved, peak, unit, frac, traffic) and the cpu_baseline object (value, unit, cores, kind, sample)
+    -- and value consistent with ms_per_step."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--graph", "ba", "--nodes", "20000",
+                        "--cpu-seconds", "1.5", "--configs", "none"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert "vs_baseline" in d and d["vs_baseline"] is None            # BASELINE.md holds no published number for this metric
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["data"].startswith("synthetic")
+    assert "node-pairs" in d["metric"] and d["unit"] == "node-pairs/s" and "workload" in d["config"] and "model" not in d["config"]
+    n = d["config"]["nodes"]
+    assert abs(d["value"] - n * (n - 1) / 2.0 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and isinstance(c["sample"], str)
+    assert d["parity"]["ok"] is True and d["parity"]["tol"] == 1e-6
