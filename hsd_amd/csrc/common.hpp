@@ -157,6 +157,21 @@ struct hsd_ctx {
     struct TileList { int tiles_i, tiles_j, sym, group; void *d; int count; };
     std::vector<TileList> tile_lists;
 
+    // pruned k-nearest sweep (raw fp64 W1; csrc/pair.hip, tk_*): a node-permuted copy of the operands (similar nodes adjacent), built on the first
+    // hsd_pair_topk of a prepared distance and released with the operands
+    int l1_cols_per_layer = 0;         // PAIR_L1_F64: columns of one histogram layer (the layers follow one another)
+    bool tk_ready = false;
+    int32_t *d_tk_orig = nullptr;      // [npad] original node of a position, -1 at padding positions
+    double *d_tk_X = nullptr;          // [dcols][npad]
+    double *d_tk_H = nullptr;          // [npad] ring-0 values in permuted order
+    double *d_tk_lo = nullptr, *d_tk_hi = nullptr;   // [tk_nf][tk_nt] feature intervals of the 128-position tiles
+    int tk_nf = 0, tk_nt = 0;
+    void *d_tk_list = nullptr;         // int2[tk_list_cap]: a launch's surviving tile pairs
+    void *d_tk_band = nullptr;         // int2[tk_band_n]: the first launch's tiles (t, t) and (t, t + 1)
+    int tk_list_cap = 0, tk_band_n = 0;
+    int *d_tk_count = nullptr;
+    uint16_t *d_tk_tmax = nullptr;     // [tk_nt]
+
     // grow-only scratch arena (top-k candidate lists, threshold sample)
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;

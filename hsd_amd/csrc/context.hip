@@ -52,6 +52,8 @@ const HsdHookInfo hsd_hook_table[H_COUNT] = {
     {"HSD_DEBUG", "ablation bits of the pair kernels: 1 no stores, 2 no arithmetic, 16 stores stay in L2; 4 / 8 only in -DHSD_STAMPS builds"},
     {"HSD_SIDE_STREAMS", "0 = the three regions of a row block in sequence instead of side by side (three-launch form only)"},
     {"HSD_TOPK_DEBUG", "fused k-nearest consumer: 1 = sweep without its candidate epilogue (timing only: the call then fails)"},
+    {"HSD_TOPK_PRUNE", "fused k-nearest consumer, raw fp64 W1 over the whole graph: 0 | 1 = never / always the pruned sweep on node-permuted operands (default: whenever the persistent kernel takes the region)"},
+    {"HSD_TOPK_GROUPS", "pruned k-nearest sweep: column groups per layer in the lower bound (1..8, default 1); read when the permuted operands are built"},
     {"HSD_TOPK_PHASES", "fused k-nearest consumer: number of equal phases of the sweep"},
     {"HSD_TOPK_GEOM", "fused k-nearest consumer: 0 | 1 = never / always the geometric launch schedule"},
     {"HSD_TOPK_CAP", "fused k-nearest consumer: capacity of a row's candidate list (overflow -> retry path)"},
@@ -128,6 +130,18 @@ void hsd_release_operands(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_rmax);
     hsd_dev_free(ctx->d_rmax16);
     hsd_dev_free(ctx->d_suf);
+    hsd_dev_free(ctx->d_tk_orig);
+    hsd_dev_free(ctx->d_tk_X);
+    hsd_dev_free(ctx->d_tk_H);
+    hsd_dev_free(ctx->d_tk_lo);
+    hsd_dev_free(ctx->d_tk_hi);
+    if (ctx->d_tk_list) (void)hipFree(ctx->d_tk_list);
+    if (ctx->d_tk_band) (void)hipFree(ctx->d_tk_band);
+    ctx->d_tk_list = ctx->d_tk_band = nullptr;
+    hsd_dev_free(ctx->d_tk_count);
+    hsd_dev_free(ctx->d_tk_tmax);
+    ctx->tk_ready = false;
+    ctx->tk_list_cap = ctx->tk_band_n = ctx->tk_nf = ctx->tk_nt = 0;
     for (auto &g : ctx->gran_lists) { (void)hipFree(g.d_gl); (void)hipFree(g.d_tmax); }
     ctx->gran_lists.clear();
     ctx->gran_order.clear();

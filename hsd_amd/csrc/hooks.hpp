@@ -40,6 +40,8 @@ enum HsdHook {
     H_DEBUG,
     H_SIDE_STREAMS,
     H_TOPK_DEBUG,
+    H_TOPK_PRUNE,
+    H_TOPK_GROUPS,
     H_TOPK_PHASES,
     H_TOPK_GEOM,
     H_TOPK_CAP,

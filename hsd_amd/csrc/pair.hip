@@ -104,6 +104,14 @@ struct PairArgs {
     int *cand_idx;          // [n][cand_cap]
     double *cand_val;       // [n][cand_cap]
     int cand_cap;
+    // pruned k-nearest sweep (raw fp64 W1, hsd_pair_topk): the operands are a node-PERMUTED copy (similar nodes adjacent), the kernel
+    // appends ORIGINAL node ids (orig_of[position]; < 0: a padding position, never a candidate); host side: an explicit tile list
+    // instead of tile_order's, and per-tile feature intervals that let launch_region drop tile pairs no row's threshold can reach
+    const int32_t *orig_of;
+    const int2 *explicit_tiles;     // host side only
+    int n_explicit;
+    const double *prune_lo, *prune_hi;   // host side only: [prune_nf][prune_nt]
+    int prune_nf, prune_nt, prune_drop_band;
 };
 
 enum { K_L1 = 0, K_SAD = 1, K_ZP = 2, K_DOT = 3, K_SAD16 = 4 };
@@ -629,13 +637,14 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
                 const int64_t j = j0 + wj + 16 * (cc >> 1) + (cc & 1);
                 if (j >= a.j_end || i == j || (diag && i > j)) continue;
                 const double v = acc[r][cc];
-                if (v <= ti_) {
+                const int jo = a.orig_of ? a.orig_of[j] : (int)j, io = a.orig_of ? a.orig_of[i] : (int)i;   // (permuted operands: original ids)
+                if (v <= ti_ && jo >= 0) {
                     const int slot = atomicAdd(a.cand_cnt + i, 1);
-                    if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
+                    if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = jo; a.cand_val[i * a.cand_cap + slot] = v; }
                 }
-                if (v <= tj_[cc]) {
+                if (v <= tj_[cc] && io >= 0) {
                     const int slot = atomicAdd(a.cand_cnt + j, 1);
-                    if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
+                    if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = io; a.cand_val[j * a.cand_cap + slot] = v; }
                 }
             }
         }
@@ -1515,8 +1524,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                         const int64_t j = (int64_t)16 * GJ[cc >> 1] + 2 * lx + (cc & 1);
                         const double v = ACC(r, cc);
                         if (v <= ti_ && i != j) {
-                            const int slot = atomicAdd(a.cand_cnt + i, 1);
-                            if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = (int)j; a.cand_val[i * a.cand_cap + slot] = v; }
+                            const int jo = a.orig_of ? a.orig_of[j] : (int)j;       // (permuted operands: the list holds original node ids)
+                            if (jo >= 0) {
+                                const int slot = atomicAdd(a.cand_cnt + i, 1);
+                                if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = jo; a.cand_val[i * a.cand_cap + slot] = v; }
+                            }
                         }
                     }
                 }
@@ -1532,8 +1544,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                             const int64_t i = (int64_t)16 * GI[r >> 1] + 2 * ly + (r & 1);
                             const double v = ACC(r, cc);
                             if (v <= tj_) {
-                                const int slot = atomicAdd(a.cand_cnt + j, 1);
-                                if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = (int)i; a.cand_val[j * a.cand_cap + slot] = v; }
+                                const int io = a.orig_of ? a.orig_of[i] : (int)i;
+                                if (io >= 0) {
+                                    const int slot = atomicAdd(a.cand_cnt + j, 1);
+                                    if (slot < a.cand_cap) { a.cand_idx[j * a.cand_cap + slot] = io; a.cand_val[j * a.cand_cap + slot] = v; }
+                                }
                             }
                         }
                     }
@@ -2061,6 +2076,77 @@ __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, i
 }
 
 
+// ---- pruned k-nearest sweep (raw fp64 W1): features, permuted operands, tile filter ---------------------------------------------
+// Any partition of the columns gives a lower bound of an L1 distance: sum_c |x_c - y_c| >= sum_g |sum_{c in g} x_c - sum_{c in g} y_c|.
+// One group per layer (for the columns G = CDF x bin width that is |mean_i - mean_j| of the ring's values, the classic W1 bound) plus the
+// ring-0 point value: F[f][i], f < nl: sum of layer f's columns of node i; f == nl (if H): H[i].
+// (G > 1: every layer's columns in G consecutive groups -- a tighter bound, more features)
+__global__ void tk_feature_kernel(const double *__restrict__ X, int64_t npad, int64_t n, int cpl, int nl, int G, const double *__restrict__ H,
+                                  double *__restrict__ F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int s = 0; s < nl; ++s)
+        for (int g = 0; g < G; ++g) {
+            double t = 0.0;
+            const int c0 = s * cpl + (int)((int64_t)cpl * g / G), c1 = s * cpl + (int)((int64_t)cpl * (g + 1) / G);
+            for (int c = c0; c < c1; ++c) t += X[(int64_t)c * npad + i];
+            F[(int64_t)(s * G + g) * n + i] = t;
+        }
+    if (H) F[(int64_t)nl * G * n + i] = H[i];
+}
+
+// Xp[c][p] = X[c][orig[p]] (0 at padding positions); blockIdx.y = column
+__global__ void tk_gather_kernel(const double *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, double *__restrict__ Xp) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    const int32_t o = orig[p];
+    const int64_t c = blockIdx.y;
+    Xp[c * npad + p] = o >= 0 ? X[c * npad + o] : 0.0;
+}
+
+// largest threshold (bfloat16 patterns of non-negative values order like the values) among a tile's 128 positions
+__global__ void tk_tilemax_kernel(const uint16_t *__restrict__ tau16, int ntiles, uint16_t *__restrict__ tmax) {
+    const int t = blockIdx.x, l = threadIdx.x;          // 64 threads
+    if (t >= ntiles) return;
+    unsigned m = max((unsigned)tau16[(int64_t)t * 128 + l], (unsigned)tau16[(int64_t)t * 128 + 64 + l]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if (l == 0) tmax[t] = (uint16_t)m;
+}
+
+// keeps the tile pairs of a list that some row's threshold can still reach: lower bound of every pair of the two tiles (sum over the
+// features of the gap between their intervals) against the larger of the two tiles' largest thresholds.  drop_band: pairs |ti - tj| <= 1
+// are dropped as well (the first launch of the pruned sweep has already evaluated them).  The order of the output is whatever the
+// atomics give: the sweep's results are sets.
+__global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const double *__restrict__ lo, const double *__restrict__ hi, int nf, int nt,
+                                 const uint16_t *__restrict__ tmax, int drop_band, int2 *__restrict__ out, int *__restrict__ count) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_in) return;
+    const int2 t = in[k];
+    const int ti = t.x & TILE_INDEX_MASK, tj = t.y;
+    if (drop_band && abs(tj - ti) <= 1) return;
+    double lb = 0.0;
+    for (int f = 0; f < nf; ++f) {
+        const double a0 = lo[(int64_t)f * nt + ti], a1 = hi[(int64_t)f * nt + ti], b0 = lo[(int64_t)f * nt + tj], b1 = hi[(int64_t)f * nt + tj];
+        lb += fmax(0.0, fmax(a0 - b1, b0 - a1));
+    }
+    const unsigned m = max((unsigned)tmax[ti], (unsigned)tmax[tj]);
+    const double thr = (double)__uint_as_float(m << 16);
+    // (the bound and the kernel's distances are sums of the same terms in different orders: a relative 1e-9 covers the rounding of both)
+    if (lb * (1.0 - 1e-9) - 1e-9 <= thr) out[atomicAdd(count, 1)] = t;
+}
+
+// out[orig[p]] = in[p] for the rows p of real nodes (k entries per row)
+__global__ void tk_unpermute_kernel(const int32_t *__restrict__ orig, int64_t npos, int k, const int *__restrict__ idx_in, const double *__restrict__ val_in,
+                                    int *__restrict__ idx_out, double *__restrict__ val_out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npos * k) return;
+    const int64_t p = e / k, q = e % k;
+    const int32_t o = orig[p];
+    if (o < 0) return;
+    idx_out[(int64_t)o * k + q] = idx_in[e];
+    val_out[(int64_t)o * k + q] = val_in[e];
+}
+
 // The granule list of up to three node ranges [r[0], r[1]) + [r[2], r[3]) + [r[4], r[5]) taken one after the other (each begins on a
 // granule and is a whole number of 128-node tiles; empty ranges are skipped): the granules of each range in the order
 // hsd_pair_prepare chose for the graph (HSD_GRAN_SORT=0: natural order), with the per-tile maxima of the rank segments.  Cached per
@@ -2152,7 +2238,9 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
             // kernel's masks (natural composition: the KL kinds have no sorted order).
             const bool diag_masked = a.sym && !wass;
             int n_in = -1, n_mask = 0;
-            const int2 *l_in = tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, diag_masked ? 1 : 0, false, false, &n_in, a.phase, a.n_phases, a.phase_w);
+            const int2 *l_in = nullptr;
+            if (a.explicit_tiles) { l_in = a.explicit_tiles; n_in = a.n_explicit; }       // (the pruned k-nearest sweep's first launch)
+            else l_in = tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, diag_masked ? 1 : 0, false, false, &n_in, a.phase, a.n_phases, a.phase_w);
             const int2 *l_mask = diag_masked ? tile_order(ctx, b.tiles_i, b.tiles_j, a.sym, 2, false, false, &n_mask, a.phase, a.n_phases, a.phase_w) : nullptr;
             if (!l_in && n_in < 0 && a.n_phases <= 1 && !diag_masked) {
                 // (formula order: HSD_SUPERTILE=1 or the list could not be allocated)
@@ -2175,6 +2263,21 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     // i_end) carry thresholds; the columns as well when the region is mirrored onto itself
                     hipLaunchKernelGGL(tau_bf16_up_kernel, dim3((unsigned)((a.i_end - a.i_begin + 255) / 256)), dim3(256), 0, stream, a.tau, a.i_begin, a.i_end,
                                        const_cast<uint16_t *>(a.tau16));
+                }
+                if (a.tau && a.prune_lo && l_in && n_in > 0 && ctx->d_tk_list && n_in <= ctx->tk_list_cap) {
+                    // pruned sweep: drop the tile pairs that no row's CURRENT threshold can reach (tk_filter_kernel); the count comes
+                    // back to the host -- one small synchronisation per launch of the sweep
+                    int kept = 0;
+                    hipLaunchKernelGGL(tk_tilemax_kernel, dim3((unsigned)a.prune_nt), dim3(64), 0, stream, a.tau16 + a.i_begin, a.prune_nt, ctx->d_tk_tmax);
+                    e = hipMemsetAsync(ctx->d_tk_count, 0, sizeof(int), stream);
+                    hipLaunchKernelGGL(tk_filter_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, l_in, n_in, a.prune_lo, a.prune_hi, a.prune_nf,
+                                       a.prune_nt, ctx->d_tk_tmax, a.prune_drop_band, reinterpret_cast<int2 *>(ctx->d_tk_list), ctx->d_tk_count);
+                    if (e == hipSuccess) e = hipMemcpyAsync(&kept, ctx->d_tk_count, sizeof(int), hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                    if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "k-nearest tile filter: %s", hipGetErrorString(e));
+                    if (hsd_hook(H_TOPK_VERBOSE)) fprintf(stderr, "[hsd topk] pruned launch: %d of %d tile pairs kept\n", kept, n_in);
+                    b.tiles = reinterpret_cast<const int2 *>(ctx->d_tk_list);
+                    b.ntiles = n_in = kept;
                 }
                 if (n_in > 0) {
                     if (a.tau)
@@ -2635,6 +2738,7 @@ int prepare_w1_raw(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int n
     hipLaunchKernelGGL(prep_l1_kernel, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, 0, cpl, ctx->d_H);
     ctx->mode = PAIR_L1_F64;
     ctx->n_seg = 0;
+    ctx->l1_cols_per_layer = cpl;
     return HSD_OK;
 }
 
@@ -3399,6 +3503,196 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
 //   2. sweep    : the normal tile kernel; its epilogue appends (j, v) with v <= tau_i to row i
 //   3. select   : per row the k smallest (value, index) candidates
 // Retries with a larger subset / capacity if a candidate list overflowed (heavy ties).
+// ------------------------------------------------------------------------------------------
+// Pruned k-nearest sweep (raw fp64 W1 -- Variant A -- over the whole graph).  The unpruned sweep evaluates every tile pair: 2 x 721 fp64
+// instructions per pair, 215 ms at BA N = 100k, although under the true k-th-nearest thresholds an exact lower bound excludes 96 % of the
+// PAIRS (tools_dev/sim/prune_pairlevel.py).  Tiles of 128 consecutive nodes are too mixed for that bound to exclude a single TILE pair; tiles
+// of 128 SIMILAR nodes are not (tools_dev/sim/prune_sim_a.py: 47 % of the tile pairs survive the first thresholds, 37 % tightened ones).
+// So this consumer -- which writes no matrix and is therefore free to order the nodes as it likes -- works on a node-PERMUTED copy of the
+// operands:
+//   features   per node, the sum of each layer's columns (|difference| = |mean_i - mean_j| of the ring's values, a lower bound of that
+//              layer's W1; any grouping of the columns bounds an L1 distance from below) and the ring-0 value: tk_feature_kernel
+//   order      a k-d order of the nodes on those features (host: median splits along the widest feature down to 128-node leaves)
+//   operands   Xp[c][position] = X[c][node at that position], padded with zero columns to a whole number of tiles: no strips; the
+//              padding positions never enter a list (orig_of < 0)
+//   launch 0   the tile pairs (t, t) and (t, t + 1) under thresholds of +inf: every row collects the ~383 nodes next to it in the order --
+//              its most similar ones -- and the first compaction leaves a threshold within a small factor of the true one (the sampled
+//              columns of the unpruned sweep give the 2 % quantile of a row)
+//   launches   the usual anti-diagonal phases, each filtered on the device (tk_filter_kernel) against the thresholds of the moment
+// The candidate lists hold ORIGINAL node ids (ties are broken by them), the rows are un-permuted at the end: the result is the one the
+// unpruned sweep gives, bit for bit (tests/test_gpu_topk.py).  HSD_TOPK_PRUNE=0 / 1: never / whenever the kind allows.
+// ------------------------------------------------------------------------------------------
+int tk_prepare(hsd_ctx *ctx) {
+    if (ctx->tk_ready) return HSD_OK;
+    const int64_t n = ctx->n, npad = ctx->npad;
+    const int cpl = ctx->l1_cols_per_layer, nl = cpl > 0 ? ctx->dcols_alg / cpl : 0;
+    const int G = std::max(1, std::min(8, hsd_hook_int(H_TOPK_GROUPS, 1)));
+    const int nf = nl * G + (ctx->has_point ? 1 : 0);
+    if (nf < 1 || npad % 128 != 0) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: nothing to order the nodes by");
+    const int nt = (int)(npad / 128);
+    // features -> host
+    std::vector<double> F((size_t)nf * n);
+    {
+        DevTmp dF;
+        HSD_TMP_ALLOC(ctx, dF, F.size() * sizeof(double));
+        hipLaunchKernelGGL(tk_feature_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, n, cpl, nl, G,
+                           ctx->has_point ? (const double *)ctx->d_H : nullptr, dF.as<double>());
+        HSD_HIP(ctx, hipMemcpyAsync(F.data(), dF.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // k-d order: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by node id
+    std::vector<int32_t> idx((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int32_t)i;
+    {
+        std::vector<std::pair<int64_t, int64_t>> todo{{0, n}};
+        while (!todo.empty()) {
+            const auto [lo, hi] = todo.back();
+            todo.pop_back();
+            if (hi - lo <= 128) continue;
+            int best = 0;
+            double ext = -1.0;
+            for (int f = 0; f < nf; ++f) {
+                double mn = INFINITY, mx = -INFINITY;
+                for (int64_t q = lo; q < hi; ++q) { const double v = F[(size_t)f * n + idx[(size_t)q]]; mn = std::min(mn, v); mx = std::max(mx, v); }
+                if (mx - mn > ext) { ext = mx - mn; best = f; }
+            }
+            int64_t mid = lo + ((hi - lo) / 2 + 127) / 128 * 128;
+            if (mid >= hi) mid = lo + (hi - lo) / 2;
+            const double *fv = F.data() + (size_t)best * n;
+            std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                             [fv](int32_t x, int32_t y) { return fv[x] < fv[y] || (fv[x] == fv[y] && x < y); });
+            todo.push_back({lo, mid});
+            todo.push_back({mid, hi});
+        }
+    }
+    std::vector<int32_t> orig((size_t)npad, -1);
+    std::copy(idx.begin(), idx.end(), orig.begin());
+    std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY);
+    for (int64_t p = 0; p < n; ++p)
+        for (int f = 0; f < nf; ++f) {
+            const double v = F[(size_t)f * n + idx[(size_t)p]];
+            double &a = flo[(size_t)f * nt + p / 128], &b = fhi[(size_t)f * nt + p / 128];
+            a = std::min(a, v); b = std::max(b, v);
+        }
+    std::vector<int2> band;
+    for (int t = 0; t < nt; ++t) { band.push_back(make_int2(t, t)); if (t + 1 < nt) band.push_back(make_int2(t, t + 1)); }
+    int rc;
+    const size_t xcnt = (size_t)std::max(ctx->dcols, 16) * npad;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, xcnt))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npad))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, flo.size()))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, fhi.size()))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
+    ctx->tk_list_cap = (int)std::min<int64_t>((int64_t)nt * (nt + 1) / 2, 0x7fffffff);
+    HSD_HIP(ctx, hipMalloc(&ctx->d_tk_list, (size_t)ctx->tk_list_cap * sizeof(int2)));
+    HSD_HIP(ctx, hipMalloc(&ctx->d_tk_band, band.size() * sizeof(int2)));
+    ctx->tk_band_n = (int)band.size();
+    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_lo, flo.data(), flo.size() * sizeof(double), hipMemcpyHostToDevice));
+    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_hi, fhi.data(), fhi.size() * sizeof(double), hipMemcpyHostToDevice));
+    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(tk_gather_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)std::max(ctx->dcols, 16)), dim3(256), 0, ctx->stream, (const double *)ctx->d_X,
+                       npad, ctx->d_tk_orig, ctx->d_tk_X);
+    if (ctx->has_point)
+        hipLaunchKernelGGL(tk_gather_kernel, dim3((unsigned)((npad + 255) / 256), 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, ctx->d_tk_H);
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tk_nf = nf; ctx->tk_nt = nt;
+    ctx->tk_ready = true;
+    return HSD_OK;
+}
+
+// *done = false: not applicable (or a list overflowed): the caller runs the unpruned sweep
+int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *done) {
+    *done = false;
+    const int64_t n = ctx->n, npad = ctx->npad;
+    PairArgs a{};
+    a.npad = npad;
+    a.dcols = ctx->dcols;
+    a.n_seg = 0;
+    a.list_cap = ctx->list_cap;
+    a.dcols_valid = ctx->dcols_alg;
+    { const char *e = hsd_hook(H_TOPK_DEBUG); a.dbg = e ? atoi(e) : 0; }
+    a.rbase = 0;
+    a.i_begin = 0; a.i_end = npad; a.j_begin = 0; a.j_end = npad;
+    a.sym = 1; a.mirror = 1;
+    {
+        PairArgs probe = a;
+        probe.tau = reinterpret_cast<const double *>(ctx);          // (any non-null value: the k-nearest kernels have no output alignment to check)
+        if (!stream_waves(ctx, probe)) return HSD_OK;
+    }
+    int rc = tk_prepare(ctx);
+    if (rc) return rc;
+    a.X = a.Y = ctx->d_tk_X;
+    a.point = ctx->has_point ? ctx->d_tk_H : nullptr;
+    a.orig_of = ctx->d_tk_orig;
+    const int64_t rows = npad;
+    const int64_t cap = std::max<int64_t>(2048, 512 + 8 * (int64_t)k);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t oTau = carve((size_t)rows * sizeof(double)), oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
+    const size_t oVal = carve((size_t)rows * cap * sizeof(double)), oOi = carve((size_t)rows * k * sizeof(int)), oOv = carve((size_t)rows * k * sizeof(double));
+    const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64), oFi = carve((size_t)n * k * sizeof(int)), oFv = carve((size_t)n * k * sizeof(double));
+    if (ctx->scratch_bytes < off) {
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        HSD_HIP(ctx, hipMalloc(&ctx->d_scratch, off));
+        ctx->scratch_bytes = off;
+    }
+    char *base = static_cast<char *>(ctx->d_scratch);
+    double *d_tau = reinterpret_cast<double *>(base + oTau), *d_val = reinterpret_cast<double *>(base + oVal), *d_oval = reinterpret_cast<double *>(base + oOv);
+    double *d_fval = reinterpret_cast<double *>(base + oFv);
+    int *d_cnt = reinterpret_cast<int *>(base + oCnt), *d_idx = reinterpret_cast<int *>(base + oIdx), *d_oidx = reinterpret_cast<int *>(base + oOi);
+    int *d_fidx = reinterpret_cast<int *>(base + oFi);
+    HSD_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)rows * sizeof(int), ctx->stream));
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_tau, rows, (double)INFINITY);
+    PairArgs b = a;
+    b.tau = d_tau; b.cand_cnt = d_cnt; b.cand_idx = d_idx; b.cand_val = d_val; b.cand_cap = (int)cap;
+    b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16);
+    const int BT = tile_edge(ctx);
+    const size_t cmp_lds = (size_t)4 * k * 12;
+    // launch 0: every row against the tiles next to its own in the order, under thresholds of +inf; then the first real thresholds
+    b.explicit_tiles = reinterpret_cast<const int2 *>(ctx->d_tk_band); b.n_explicit = ctx->tk_band_n;
+    if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
+    hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
+    // the rest of the pair space in anti-diagonal phases, each filtered against the thresholds of the moment (tightened after phases 1, 2, 4)
+    b.explicit_tiles = nullptr; b.n_explicit = 0;
+    b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = 1;
+    int n_phases = 8;
+    if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
+    for (int ph = 0; ph < n_phases; ++ph) {
+        b.phase = ph; b.phase_w = 1; b.n_phases = n_phases;
+        if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
+        if (ph + 1 < n_phases && ((ph + 1) & ph) == 0)
+            hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
+    }
+    // select (the rows of real nodes are the first n positions), back to node order, out
+    int flag[4] = {0, 0, 0, 0};
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap, (int64_t)0, n, k, d_oidx, d_oval,
+                       ctx->d_flag);
+    hipLaunchKernelGGL(tk_unpermute_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig, n, k, d_oidx, d_oval, d_fidx, d_fval);
+    HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    HSD_HIP(ctx, hipGetLastError());
+    if (hsd_hook(H_TOPK_VERBOSE)) {
+        std::vector<int> hc((size_t)n);
+        (void)hipMemcpy(hc.data(), d_cnt, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+        int64_t mx = 0;
+        for (int v : hc) mx = std::max<int64_t>(mx, v);
+        fprintf(stderr, "[hsd topk] pruned sweep: capacity %lld, longest list %lld, overflow %d\n", (long long)cap, (long long)mx, flag[0] & 1);
+    }
+    if (flag[0] & 1) return HSD_OK;                 // a list overflowed (or came up short): the unpruned sweep takes the call
+    HSD_HIP(ctx, hipMemcpyAsync(idx_out, d_fidx, (size_t)n * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipMemcpyAsync(dist_out, d_fval, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *done = true;
+    return HSD_OK;
+}
+
 extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
@@ -3411,6 +3705,15 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     if (!idx_out || !dist_out) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
     const int64_t rows = r1 - r0;
     const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
+    {
+        // raw fp64 W1 over the whole graph: the pruned sweep on node-permuted operands (above) where it applies
+        const int pr = hsd_hook_int(H_TOPK_PRUNE, -1);
+        if (ctx->mode == PAIR_L1_F64 && r0 == 0 && r1 == n && k <= 128 && ctx->l1_cols_per_layer > 0 && pr != 0 && !hsd_hook(H_TOPK_GEOM)) {
+            bool done = false;
+            const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);
+            if (rcp != HSD_OK || done) return rcp;
+        }
+    }
 
     PairArgs a{};
     a.X = ctx->d_X;

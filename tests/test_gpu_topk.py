@@ -184,3 +184,96 @@ def test_topk_against_the_oracle_directly(engine, mode, align, lo, hi, stream):
     assert clear.mean() > 0.5                     # (the comparison below must not be vacuous)
     same = np.array([set(idx[r]) == set(order[r, :k]) for r in np.nonzero(clear)[0]])
     assert same.all(), int((~same).sum())
+
+
+def _env(**kw):
+    import os
+
+    class _E:
+        def __enter__(self):
+            self.old = {k: os.environ.get(k) for k in kw}
+            os.environ.update({k: str(v) for k, v in kw.items()})
+
+        def __exit__(self, *exc):
+            for k, v in self.old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _E()
+
+
+@pytest.mark.parametrize("n,k", [(20000 + 77, 20), (17000, 1), (16512, 128)])
+def test_pruned_sweep_equals_the_unpruned_one(engine, capfd, n, k):
+    """Raw fp64 W1 over the whole graph takes the PRUNED sweep by default once the persistent kernel takes the region (node-permuted operands,
+    k-d order, band thresholds, per-launch tile filter): its (distance, index) lists are those of the unpruned sweep bit for bit -- ties by the
+    ORIGINAL node id -- and sampled rows equal a lexicographic selection on rows of the matrix.  The verbose log must show that tile pairs were
+    in fact dropped."""
+    from hsd_amd.graph import barabasi_albert
+    g = barabasi_albert(n, 5, 7)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 0, 0, 3)
+    with _env(HSD_TOPK_PRUNE=0):
+        ridx, rval = engine.pair_topk(k)
+    with _env(HSD_TOPK_VERBOSE=1):
+        capfd.readouterr()
+        idx, val = engine.pair_topk(k)
+        log = capfd.readouterr().err
+    kept = [tuple(int(x) for x in ln.split(":")[1].split("tile")[0].split("of")) for ln in log.splitlines() if "pruned launch" in ln]
+    assert kept and sum(a for a, b in kept) < (0.9 if k > 64 else 0.7) * sum(b for a, b in kept), log[-600:]
+    assert "overflow 0" in log
+    assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
+    M = engine.pair_rows_device()
+    try:
+        for row in (0, 129, n // 2, n - 1):
+            d = M.rows_to_host(row, row + 1)[0].copy()
+            d[row] = np.inf
+            order = np.lexsort((np.arange(n), d))[:k]
+            assert np.array_equal(order, idx[row]) and np.array_equal(d[order], val[row])
+    finally:
+        M.free()
+
+
+@pytest.mark.parametrize("n,k", [(100, 9), (128, 5), (129, 40), (700, 16), (2222, 20)])
+def test_pruned_sweep_small_and_ragged(engine, n, k):
+    """The pruned sweep forced onto small graphs (HSD_STREAM=1, HSD_TOPK_PRUNE=1): fewer than one tile, exactly one, one node more, sizes that
+    are no multiple of 128 (padding positions share the last tile and must never become a neighbour), a star's hub among them."""
+    from hsd_amd.graph import Graph, barabasi_albert
+    if n == 700:
+        # two stars joined at their hubs: hundreds of leaves with identical rings (exact ties, broken by the ORIGINAL node id) and two hubs
+        half = n // 2
+        src = np.concatenate([[0], np.zeros(half - 1, dtype=np.int64), np.full(n - half - 1, half, dtype=np.int64)])
+        dst = np.concatenate([[half], np.arange(1, half), np.arange(half + 1, n)])
+        g = Graph.from_edges(list(range(n)), src, dst)
+    else:
+        g = barabasi_albert(n, 3, 5)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(2)
+    engine.pair_prepare(0, 0, 0, 2)
+    D = engine.pair_rows_host()
+    ridx, rval = _reference_topk(D, k)
+    with _env(HSD_STREAM=1, HSD_TOPK_PRUNE=1):
+        idx, val = engine.pair_topk(k)
+    assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
+
+
+def test_pruned_sweep_falls_back_when_a_list_overflows(engine, capfd):
+    """A node order that does not fit the distance (eight column groups per layer as features: HSD_TOPK_GROUPS=8) leaves loose first thresholds and
+    overflowing lists on a scale-free graph: the call must notice, hand over to the unpruned sweep and still return the exact result."""
+    from hsd_amd.graph import barabasi_albert
+    n, k = 24000, 20
+    g = barabasi_albert(n, 5, 11)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    with _env(HSD_TOPK_PRUNE=0):
+        engine.pair_prepare(0, 0, 0, 3)
+        ridx, rval = engine.pair_topk(k)
+    with _env(HSD_TOPK_GROUPS=8, HSD_TOPK_VERBOSE=1):
+        engine.pair_prepare(0, 0, 0, 3)                       # (the permuted operands are rebuilt with the operands)
+        capfd.readouterr()
+        idx, val = engine.pair_topk(k)
+        log = capfd.readouterr().err
+    assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
+    if "overflow 1" in log:
+        assert "attempt 0" in log                            # the unpruned sweep ran after it
