@@ -507,8 +507,10 @@ def fused_knn(eng, mat, n, k):
     of the resident matrix: same distances, ties by index."""
     if n <= k + 1:
         return None
-    eng.pair_topk(k)                                   # warm (lists, scratch)
     eng.sync()
+    t0 = time.perf_counter()
+    eng.pair_topk(k)                                   # first call: scratch allocation; raw fp64 W1: + the one-time node order / permuted operands
+    dt_first = time.perf_counter() - t0
     t0 = time.perf_counter()
     idx, val = eng.pair_topk(k)
     dt = time.perf_counter() - t0
@@ -518,8 +520,9 @@ def fused_knn(eng, mat, n, k):
         d[r] = np.inf
         order = np.lexsort((np.arange(n), d))[:k]
         ok = ok and bool(np.array_equal(order, idx[r]) and np.array_equal(d[order], val[r]))
-    return dict(call="hsd_pair_topk", k=k, ms_end_to_end=round(dt * 1e3, 3), rows_checked_against_matrix=3, exact=ok,
-                note="k nearest of every row without forming the matrix; time includes the results' copy to host memory")
+    return dict(call="hsd_pair_topk", k=k, ms_end_to_end=round(dt * 1e3, 3), ms_first_call=round(dt_first * 1e3, 3), rows_checked_against_matrix=3, exact=ok,
+                note="k nearest of every row without forming the matrix; time includes the results' copy to host memory (raw fp64 W1 over the whole "
+                     "graph: the pruned sweep on node-permuted operands; its one-time setup is in ms_first_call)")
 
 
 def row_block_rehearsal(eng, mat, n, kernel_ms, heavy):

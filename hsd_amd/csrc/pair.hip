@@ -2080,19 +2080,28 @@ __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, i
 // Any partition of the columns gives a lower bound of an L1 distance: sum_c |x_c - y_c| >= sum_g |sum_{c in g} x_c - sum_{c in g} y_c|.
 // One group per layer (for the columns G = CDF x bin width that is |mean_i - mean_j| of the ring's values, the classic W1 bound) plus the
 // ring-0 point value: F[f][i], f < nl: sum of layer f's columns of node i; f == nl (if H): H[i].
-// (G > 1: every layer's columns in G consecutive groups -- a tighter bound, more features)
-__global__ void tk_feature_kernel(const double *__restrict__ X, int64_t npad, int64_t n, int cpl, int nl, int G, const double *__restrict__ H,
-                                  double *__restrict__ F) {
+// (G > 1: every layer's columns in G consecutive groups -- a tighter bound, more features).  Two steps so that the sums have one fixed
+// order: blockIdx.y = feature x TK_SLICES + slice -> partial sums P[feature][slice][i]; then F[feature][i] = the slices added in order.
+constexpr int TK_SLICES = 16;
+__global__ void tk_feature_partial_kernel(const double *__restrict__ X, int64_t npad, int64_t n, int cpl, int G, double *__restrict__ P) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int s = 0; s < nl; ++s)
-        for (int g = 0; g < G; ++g) {
-            double t = 0.0;
-            const int c0 = s * cpl + (int)((int64_t)cpl * g / G), c1 = s * cpl + (int)((int64_t)cpl * (g + 1) / G);
-            for (int c = c0; c < c1; ++c) t += X[(int64_t)c * npad + i];
-            F[(int64_t)(s * G + g) * n + i] = t;
-        }
-    if (H) F[(int64_t)nl * G * n + i] = H[i];
+    const int f = blockIdx.y / TK_SLICES, sl = blockIdx.y % TK_SLICES, s = f / G, g = f % G;
+    const int c0 = s * cpl + (int)((int64_t)cpl * g / G), c1 = s * cpl + (int)((int64_t)cpl * (g + 1) / G);
+    const int a = c0 + (int)((int64_t)(c1 - c0) * sl / TK_SLICES), b = c0 + (int)((int64_t)(c1 - c0) * (sl + 1) / TK_SLICES);
+    double t = 0.0;
+    for (int c = a; c < b; ++c) t += X[(int64_t)c * npad + i];
+    P[((int64_t)f * TK_SLICES + sl) * n + i] = t;
+}
+__global__ void tk_feature_combine_kernel(const double *__restrict__ P, int64_t n, int nfh, const double *__restrict__ H, double *__restrict__ F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int f = 0; f < nfh; ++f) {
+        double t = 0.0;
+        for (int sl = 0; sl < TK_SLICES; ++sl) t += P[((int64_t)f * TK_SLICES + sl) * n + i];
+        F[(int64_t)f * n + i] = t;
+    }
+    if (H) F[(int64_t)nfh * n + i] = H[i];
 }
 
 // Xp[c][p] = X[c][orig[p]] (0 at padding positions); blockIdx.y = column
@@ -3524,6 +3533,16 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
 // ------------------------------------------------------------------------------------------
 int tk_prepare(hsd_ctx *ctx) {
     if (ctx->tk_ready) return HSD_OK;
+    const bool verbose = hsd_hook(H_TOPK_VERBOSE) != nullptr;
+    if (verbose) (void)hipStreamSynchronize(ctx->stream);          // (whatever hsd_pair_prepare left in flight is not this setup's time)
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!verbose) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hsd topk] setup: %-34s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int64_t n = ctx->n, npad = ctx->npad;
     const int cpl = ctx->l1_cols_per_layer, nl = cpl > 0 ? ctx->dcols_alg / cpl : 0;
     const int G = std::max(1, std::min(8, hsd_hook_int(H_TOPK_GROUPS, 1)));
@@ -3533,38 +3552,86 @@ int tk_prepare(hsd_ctx *ctx) {
     // features -> host
     std::vector<double> F((size_t)nf * n);
     {
-        DevTmp dF;
+        DevTmp dF, dP;
         HSD_TMP_ALLOC(ctx, dF, F.size() * sizeof(double));
-        hipLaunchKernelGGL(tk_feature_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, n, cpl, nl, G,
+        HSD_TMP_ALLOC(ctx, dP, (size_t)nl * G * TK_SLICES * n * sizeof(double));
+        hipLaunchKernelGGL(tk_feature_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(nl * G * TK_SLICES)), dim3(256), 0, ctx->stream,
+                           (const double *)ctx->d_X, npad, n, cpl, G, dP.as<double>());
+        hipLaunchKernelGGL(tk_feature_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dP.as<double>(), n, nl * G,
                            ctx->has_point ? (const double *)ctx->d_H : nullptr, dF.as<double>());
         HSD_HIP(ctx, hipMemcpyAsync(F.data(), dF.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    // k-d order: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by node id
+    mark("features (device -> host)");
+    // k-d order: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by node id.  Node-major copy
+    // of the features (one node's features in one cache line); once the ranges are short enough their subtrees go to host threads
+    // (disjoint ranges of idx: no sharing; a thread that cannot be created leaves its range to the caller, as in hsd_pair_prepare).
     std::vector<int32_t> idx((size_t)n);
     for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int32_t)i;
     {
-        std::vector<std::pair<int64_t, int64_t>> todo{{0, n}};
-        while (!todo.empty()) {
-            const auto [lo, hi] = todo.back();
-            todo.pop_back();
-            if (hi - lo <= 128) continue;
+        std::vector<double> A((size_t)n * nf);
+        for (int f = 0; f < nf; ++f)
+            for (int64_t i = 0; i < n; ++i) A[(size_t)i * nf + f] = F[(size_t)f * n + i];
+        const double *Ap = A.data();
+        int32_t *ip = idx.data();
+        const auto split = [Ap, ip, nf](int64_t lo, int64_t hi) -> int64_t {       // returns the split point, or -1 for a leaf
+            if (hi - lo <= 128) return -1;
             int best = 0;
             double ext = -1.0;
             for (int f = 0; f < nf; ++f) {
                 double mn = INFINITY, mx = -INFINITY;
-                for (int64_t q = lo; q < hi; ++q) { const double v = F[(size_t)f * n + idx[(size_t)q]]; mn = std::min(mn, v); mx = std::max(mx, v); }
+                for (int64_t q = lo; q < hi; ++q) { const double v = Ap[(size_t)ip[q] * nf + f]; mn = std::min(mn, v); mx = std::max(mx, v); }
                 if (mx - mn > ext) { ext = mx - mn; best = f; }
             }
             int64_t mid = lo + ((hi - lo) / 2 + 127) / 128 * 128;
             if (mid >= hi) mid = lo + (hi - lo) / 2;
-            const double *fv = F.data() + (size_t)best * n;
-            std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
-                             [fv](int32_t x, int32_t y) { return fv[x] < fv[y] || (fv[x] == fv[y] && x < y); });
-            todo.push_back({lo, mid});
-            todo.push_back({mid, hi});
+            std::nth_element(ip + lo, ip + mid, ip + hi, [Ap, nf, best](int32_t x, int32_t y) {
+                const double a = Ap[(size_t)x * nf + best], b = Ap[(size_t)y * nf + best];
+                return a < b || (a == b && x < y);
+            });
+            return mid;
+        };
+        const auto subtree = [&split](int64_t lo0, int64_t hi0) noexcept {
+            try {
+                std::vector<std::pair<int64_t, int64_t>> todo{{lo0, hi0}};
+                while (!todo.empty()) {
+                    const auto [lo, hi] = todo.back();
+                    todo.pop_back();
+                    const int64_t mid = split(lo, hi);
+                    if (mid < 0) continue;
+                    todo.push_back({lo, mid});
+                    todo.push_back({mid, hi});
+                }
+            } catch (...) {}                     // (out of memory for the work list: the range stays as it is -- a worse order, the same results)
+        };
+        // the top of the tree on this thread, down to ranges of about n / 16; then one task per range
+        std::vector<std::pair<int64_t, int64_t>> top{{0, n}}, tasks;
+        while (!top.empty()) {
+            const auto [lo, hi] = top.back();
+            top.pop_back();
+            if (hi - lo <= std::max<int64_t>(n / 16, 1024)) { tasks.push_back({lo, hi}); continue; }
+            const int64_t mid = split(lo, hi);
+            if (mid < 0) continue;
+            top.push_back({lo, mid});
+            top.push_back({mid, hi});
+        }
+        const int thr_cap = std::max(1, hsd_hook_int(H_PLAN_THREADS, 16));
+        const int n_thr = std::max(1, std::min<int>(std::min<int>((int)tasks.size(), thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
+        std::atomic<int> next{0};
+        const auto work = [&]() noexcept {
+            for (int t; (t = next.fetch_add(1, std::memory_order_relaxed)) < (int)tasks.size();) subtree(tasks[(size_t)t].first, tasks[(size_t)t].second);
+        };
+        {
+            std::vector<std::thread> pool;
+            try {
+                pool.reserve((size_t)n_thr);
+                for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
+            } catch (...) {}
+            work();
+            for (auto &th : pool) th.join();
         }
     }
+    mark("k-d order (host)");
     std::vector<int32_t> orig((size_t)npad, -1);
     std::copy(idx.begin(), idx.end(), orig.begin());
     std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY);
@@ -3576,6 +3643,7 @@ int tk_prepare(hsd_ctx *ctx) {
         }
     std::vector<int2> band;
     for (int t = 0; t < nt; ++t) { band.push_back(make_int2(t, t)); if (t + 1 < nt) band.push_back(make_int2(t, t + 1)); }
+    mark("tile intervals + first-launch list");
     int rc;
     const size_t xcnt = (size_t)std::max(ctx->dcols, 16) * npad;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
@@ -3598,6 +3666,7 @@ int tk_prepare(hsd_ctx *ctx) {
     if (ctx->has_point)
         hipLaunchKernelGGL(tk_gather_kernel, dim3((unsigned)((npad + 255) / 256), 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, ctx->d_tk_H);
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mark("allocations + permuted operands");
     ctx->tk_nf = nf; ctx->tk_nt = nt;
     ctx->tk_ready = true;
     return HSD_OK;
