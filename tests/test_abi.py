@@ -59,6 +59,7 @@ def test_environment_hooks_are_one_table_and_documented():
     assert len(hooks) >= 30
     table = open(os.path.join(csrc, "context.hip"), encoding="utf-8").read()
     design = open(os.path.join(REPO, "DESIGN.md"), encoding="utf-8").read()
+    assert re.findall(r'\{"HSD_([A-Z0-9_]+)", "', table) == hooks, "hsd_hook_table must list the hooks in the order of the enum (it is indexed by it)"
     for h in hooks:
         assert f'{{"HSD_{h}"' in table, f"HSD_{h} missing from hsd_hook_table"
         assert f"HSD_{h}" in design, f"HSD_{h} is not documented in DESIGN.md"
