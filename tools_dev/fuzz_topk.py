@@ -26,6 +26,7 @@ def soak(eng, seed=1, budget_s=90.0, max_calls=None, n_max=5000):
         eng.set_graph(g.rowptr, g.col)
         eng.signature_build_degree(hop)
         mode = [(0, 1, 0, max(hop - 1, 0)), (0, 0, 0, hop), (2, 0, 0, hop)][int(rng.integers(0, 3))]
+        if os.environ.get("FUZZ_MODE") == "A": mode = (0, 0, 0, hop)       # the raw fp64 distance only (its pruned sweep)
         try:
             eng.pair_prepare(*mode)
             D = eng.pair_rows_host()
@@ -39,7 +40,10 @@ def soak(eng, seed=1, budget_s=90.0, max_calls=None, n_max=5000):
             if rng.random() < 0.2: env["HSD_TOPK_CAP"] = str(k + int(rng.integers(1, 40)))
             if rng.random() < 0.3: env["HSD_GRAN_SORT"] = "0"
             if rng.random() < 0.2: env["HSD_U8"] = "0"          # (read at prepare time: the next graph's)
-            a = int(rng.integers(0, n - 1)) // 4 * 4 if rng.random() < 0.5 else 0
+            pr = rng.random()
+            if pr < 0.35: env["HSD_TOPK_PRUNE"] = "1"          # raw fp64 W1 over the whole graph: the pruned sweep (with HSD_STREAM=1 also on small graphs)
+            elif pr < 0.5: env["HSD_TOPK_PRUNE"] = "0"
+            a = int(rng.integers(0, n - 1)) // 4 * 4 if rng.random() < (0.5 if os.environ.get("FUZZ_MODE") != "A" else 0.15) else 0
             b = int(rng.integers(a + 1, n + 1)) if a else n
             os.environ.update(env)
             try:
