@@ -168,7 +168,7 @@ struct hsd_ctx {
     int tk_nf = 0, tk_nt = 0;
     void *d_tk_list = nullptr;         // int2[tk_list_cap]: a launch's surviving tile pairs
     void *d_tk_band = nullptr;         // int2[tk_band_n]: the first launch's tiles (t, t) and (t, t + 1)
-    int tk_list_cap = 0, tk_band_n = 0;
+    int tk_list_cap = 0, tk_band_n = 0, tk_band_w = 1;
     int *d_tk_count = nullptr;
     uint16_t *d_tk_tmax = nullptr;     // [tk_nt]
 

@@ -42,6 +42,7 @@ enum HsdHook {
     H_TOPK_DEBUG,
     H_TOPK_PRUNE,
     H_TOPK_GROUPS,
+    H_TOPK_BAND,
     H_TOPK_PHASES,
     H_TOPK_GEOM,
     H_TOPK_CAP,

@@ -2165,7 +2165,7 @@ __global__ void tk_tilemax_kernel(const uint16_t *__restrict__ tau16, int ntiles
 }
 
 // keeps the tile pairs of a list that some row's threshold can still reach: lower bound of every pair of the two tiles (sum over the
-// features of the gap between their intervals) against the larger of the two tiles' largest thresholds.  drop_band: pairs |ti - tj| <= 1
+// features of the gap between their intervals) against the larger of the two tiles' largest thresholds.  drop_band > 0: pairs |ti - tj| <= drop_band
 // are dropped as well (the first launch of the pruned sweep has already evaluated them).  The order of the output is whatever the
 // atomics give: the sweep's results are sets.
 __global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const double *__restrict__ lo, const double *__restrict__ hi, int nf, int nt,
@@ -2174,7 +2174,7 @@ __global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const do
     if (k >= n_in) return;
     const int2 t = in[k];
     const int ti = t.x & TILE_INDEX_MASK, tj = t.y;
-    if (drop_band && abs(tj - ti) <= 1) return;
+    if (drop_band && abs(tj - ti) <= drop_band) return;
     double lb = 0.0;
     for (int f = 0; f < nf; ++f) {
         const double a0 = lo[(int64_t)f * nt + ti], a1 = hi[(int64_t)f * nt + ti], b0 = lo[(int64_t)f * nt + tj], b1 = hi[(int64_t)f * nt + tj];
@@ -3683,8 +3683,11 @@ int tk_prepare(hsd_ctx *ctx) {
             double &a = flo[(size_t)f * nt + p / 128], &b = fhi[(size_t)f * nt + p / 128];
             a = std::min(a, v); b = std::max(b, v);
         }
+    const int band_w = std::max(1, std::min(4, hsd_hook_int(H_TOPK_BAND, 1)));      // the first launch: every tile with itself and its band_w successors
     std::vector<int2> band;
-    for (int t = 0; t < nt; ++t) { band.push_back(make_int2(t, t)); if (t + 1 < nt) band.push_back(make_int2(t, t + 1)); }
+    for (int t = 0; t < nt; ++t)
+        for (int d = 0; d <= band_w && t + d < nt; ++d) band.push_back(make_int2(t, t + d));
+    ctx->tk_band_w = band_w;
     mark("tile intervals + first-launch list");
     int rc;
     const size_t xcnt = (size_t)std::max(ctx->dcols, 16) * npad;
@@ -3772,8 +3775,10 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
     // the rest of the pair space in anti-diagonal phases, each filtered against the thresholds of the moment (tightened after phases 1, 2, 4)
     b.explicit_tiles = nullptr; b.n_explicit = 0;
-    b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = 1;
-    int n_phases = 8;
+    b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = ctx->tk_band_w;
+    // (measured at BA N = 100k: 2 phases overflow the lists -- the band thresholds meet half the columns at once --, 3 / 4 / 5 / 6 / 8 / 12 / 16 take
+    //  66.3 / 65.7 / 65.6 / 66.8 / 68.8 / 72.1 / 74.5 ms with longest lists of 847 / 690 / 296 / 360 / 709 entries; twice the nodes, twice the appends per phase)
+    int n_phases = ctx->tk_nt <= 1200 ? 5 : 8;
     if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
     for (int ph = 0; ph < n_phases; ++ph) {
         b.phase = ph; b.phase_w = 1; b.n_phases = n_phases;
