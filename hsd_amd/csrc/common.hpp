@@ -243,6 +243,7 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, uint32_t *
 bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop, int n_bins);
 void hsd_khop_ms_release(hsd_ctx *ctx);
 void hsd_release_operands(hsd_ctx *ctx);
+void hsd_tk_release(hsd_ctx *ctx);
 extern "C" void hsd_heat_release_internal(hsd_ctx *ctx);
 int hsd_launch_pair_rowquirk_tiled(hsd_ctx *ctx, const double *psi_dev, int64_t ldpsi, int64_t r0, int64_t r1, double *dst, int64_t dld);
 int hsd_launch_pair_ragged_tiled(hsd_ctx *ctx, int layer_lo, int layer_hi, int64_t r0, int64_t r1, double *dst, int64_t dld);

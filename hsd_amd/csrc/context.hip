@@ -121,16 +121,9 @@ extern "C" int hsd_create(int device, hsd_ctx **out) try {
     return HSD_OK;
 } HSD_ABI_GUARD(nullptr)
 
-void hsd_release_operands(hsd_ctx *ctx) {
-    if (ctx->d_X) (void)hipFree(ctx->d_X);
-    if (ctx->d_Y) (void)hipFree(ctx->d_Y);
-    ctx->d_X = ctx->d_Y = nullptr;
-    hsd_dev_free(ctx->d_H);
-    hsd_dev_free(ctx->d_inv);
-    hsd_dev_free(ctx->d_seg_tab);
-    hsd_dev_free(ctx->d_rmax);
-    hsd_dev_free(ctx->d_rmax16);
-    hsd_dev_free(ctx->d_suf);
+// the pruned k-nearest sweep's node-permuted operand copy (csrc/pair.hip, tk_prepare): released with the operands, and by tk_prepare
+// itself before it builds a new one (a failed attempt leaves nothing behind)
+void hsd_tk_release(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_tk_orig);
     hsd_dev_free(ctx->d_tk_X);
     hsd_dev_free(ctx->d_tk_H);
@@ -143,6 +136,19 @@ void hsd_release_operands(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_tk_tmax);
     ctx->tk_ready = false;
     ctx->tk_list_cap = ctx->tk_band_n = ctx->tk_nf = ctx->tk_nt = 0;
+}
+
+void hsd_release_operands(hsd_ctx *ctx) {
+    if (ctx->d_X) (void)hipFree(ctx->d_X);
+    if (ctx->d_Y) (void)hipFree(ctx->d_Y);
+    ctx->d_X = ctx->d_Y = nullptr;
+    hsd_dev_free(ctx->d_H);
+    hsd_dev_free(ctx->d_inv);
+    hsd_dev_free(ctx->d_seg_tab);
+    hsd_dev_free(ctx->d_rmax);
+    hsd_dev_free(ctx->d_rmax16);
+    hsd_dev_free(ctx->d_suf);
+    hsd_tk_release(ctx);
     for (auto &g : ctx->gran_lists) { (void)hipFree(g.d_gl); (void)hipFree(g.d_tmax); }
     ctx->gran_lists.clear();
     ctx->gran_order.clear();

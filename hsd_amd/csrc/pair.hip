@@ -3575,6 +3575,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
 // ------------------------------------------------------------------------------------------
 int tk_prepare(hsd_ctx *ctx) {
     if (ctx->tk_ready) return HSD_OK;
+    hsd_tk_release(ctx);                               // (whatever an earlier, failed attempt allocated)
     const bool verbose = hsd_hook(H_TOPK_VERBOSE) != nullptr;
     if (verbose) (void)hipStreamSynchronize(ctx->stream);          // (whatever hsd_pair_prepare left in flight is not this setup's time)
     auto t_last = std::chrono::steady_clock::now();

@@ -433,6 +433,7 @@ def test_contexts_return_their_hbm(engine):
                 eng.pair_rows_host(0, 300)
                 if mode[0] != 1:
                     eng.pair_topk(7, 100, 900)
+                    eng.pair_topk(5)                          # whole graph: raw fp64 W1 builds its node-permuted operand copy (pruned sweep)
         finally:
             os.environ.pop("HSD_STREAM", None)
         m = hsd_amd.HSD(kar, "karate", 1.0, 3, "wasserstein", engine=eng)
