@@ -3825,7 +3825,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     {
         // raw fp64 W1 over the whole graph: the pruned sweep on node-permuted operands (above) where it applies
         const int pr = hsd_hook_int(H_TOPK_PRUNE, -1);
-        if (ctx->mode == PAIR_L1_F64 && r0 == 0 && r1 == n && k <= 128 && ctx->l1_cols_per_layer > 0 && pr != 0 && !hsd_hook(H_TOPK_GEOM)) {
+        if (ctx->mode == PAIR_L1_F64 && r0 == 0 && r1 == n && k <= 128 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0 && !hsd_hook(H_TOPK_GEOM)) {
             bool done = false;
             const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);
             if (rcp != HSD_OK || done) return rcp;
