@@ -165,6 +165,14 @@ struct hsd_ctx {
     double *d_tk_X = nullptr;          // [dcols][npad]
     double *d_tk_H = nullptr;          // [npad] ring-0 values in permuted order
     double *d_tk_lo = nullptr, *d_tk_hi = nullptr;   // [tk_nf][tk_nt] feature intervals of the 128-position tiles
+    double *d_tk_scale = nullptr;      // [tk_nf][tk_nt] smallest factor of a feature's gap within a tile (zero-pad layers: 1 / ring size)
+    // zero-pad kinds: the rest of the permuted operand set
+    uint32_t *d_tk_U = nullptr;        // [dcols][npad] packed words
+    double *d_tk_inv = nullptr;        // [n_seg][npad]
+    uint32_t *d_tk_suf = nullptr;      // [suf_rows + 1][npad]
+    uint32_t *d_tk_rmax16 = nullptr;   // [n_seg][npad / 16] members above the layer's threshold per 16-position granule (| bit 31: too wide for the uint8 range)
+    int32_t *d_tk_gl = nullptr;        // [npad / 16] the positions' granules in natural order
+    uint32_t *d_tk_tmaxs = nullptr;    // [n_seg][tk_nt] per-tile maxima of d_tk_rmax16
     int tk_nf = 0, tk_nt = 0;
     void *d_tk_list = nullptr;         // int2[tk_list_cap]: a launch's surviving tile pairs
     void *d_tk_band = nullptr;         // int2[tk_band_n]: the first launch's tiles (t, t) and (t, t + 1)

@@ -129,6 +129,13 @@ void hsd_tk_release(hsd_ctx *ctx) {
     hsd_dev_free(ctx->d_tk_H);
     hsd_dev_free(ctx->d_tk_lo);
     hsd_dev_free(ctx->d_tk_hi);
+    hsd_dev_free(ctx->d_tk_scale);
+    hsd_dev_free(ctx->d_tk_U);
+    hsd_dev_free(ctx->d_tk_inv);
+    hsd_dev_free(ctx->d_tk_suf);
+    hsd_dev_free(ctx->d_tk_rmax16);
+    hsd_dev_free(ctx->d_tk_gl);
+    hsd_dev_free(ctx->d_tk_tmaxs);
     if (ctx->d_tk_list) (void)hipFree(ctx->d_tk_list);
     if (ctx->d_tk_band) (void)hipFree(ctx->d_tk_band);
     ctx->d_tk_list = ctx->d_tk_band = nullptr;

@@ -111,7 +111,11 @@ struct PairArgs {
     const int2 *explicit_tiles;     // host side only
     int n_explicit;
     const double *prune_lo, *prune_hi;   // host side only: [prune_nf][prune_nt]
+    const double *prune_scale;      // host side only: [prune_nf][prune_nt] smallest factor of the feature's gap within a tile (nullptr: 1)
     int prune_nf, prune_nt, prune_drop_band;
+    const int32_t *gl_ov;           // host side only: the region's granule list and its per-tile maxima given by the caller (permuted operands)
+    const uint32_t *tmax_ov;
+    int ntl_ov;
 };
 
 enum { K_L1 = 0, K_SAD = 1, K_ZP = 2, K_DOT = 3, K_SAD16 = 4 };
@@ -2168,7 +2172,8 @@ __global__ void tk_tilemax_kernel(const uint16_t *__restrict__ tau16, int ntiles
 // features of the gap between their intervals) against the larger of the two tiles' largest thresholds.  drop_band > 0: pairs |ti - tj| <= drop_band
 // are dropped as well (the first launch of the pruned sweep has already evaluated them).  The order of the output is whatever the
 // atomics give: the sweep's results are sets.
-__global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const double *__restrict__ lo, const double *__restrict__ hi, int nf, int nt,
+__global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const double *__restrict__ lo, const double *__restrict__ hi,
+                                 const double *__restrict__ scale, int nf, int nt,
                                  const uint16_t *__restrict__ tmax, int drop_band, int2 *__restrict__ out, int *__restrict__ count) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_in) return;
@@ -2178,12 +2183,21 @@ __global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const do
     double lb = 0.0;
     for (int f = 0; f < nf; ++f) {
         const double a0 = lo[(int64_t)f * nt + ti], a1 = hi[(int64_t)f * nt + ti], b0 = lo[(int64_t)f * nt + tj], b1 = hi[(int64_t)f * nt + tj];
-        lb += fmax(0.0, fmax(a0 - b1, b0 - a1));
+        // (zero-pad layers: the gap between the rings' value sums, divided by the larger ring -- at least the smaller of the tiles' smallest 1 / ring size)
+        lb += fmax(0.0, fmax(a0 - b1, b0 - a1)) * (scale ? fmin(scale[(int64_t)f * nt + ti], scale[(int64_t)f * nt + tj]) : 1.0);
     }
     const unsigned m = max((unsigned)tmax[ti], (unsigned)tmax[tj]);
     const double thr = (double)__uint_as_float(m << 16);
     // (the bound and the kernel's distances are sums of the same terms in different orders: a relative 1e-9 covers the rounding of both)
     if (lb * (1.0 - 1e-9) - 1e-9 <= thr) out[atomicAdd(count, 1)] = t;
+}
+
+// thresholds by node -> thresholds by position (0 at padding positions: nothing is at distance <= 0 from them but themselves)
+__global__ void tk_permute_tau_kernel(const int32_t *__restrict__ orig, int64_t npos, const double *__restrict__ tau_node, double *__restrict__ tau_pos) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const int32_t o = orig[p];
+    tau_pos[p] = o >= 0 ? tau_node[o] : 0.0;
 }
 
 // out[orig[p]] = in[p] for the rows p of real nodes (k entries per row)
@@ -2269,14 +2283,23 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
     // LDS budget of the persistent kernel (2 workgroups per CU): two tiles x three vectors x 2 KiB; deeper hierarchies
     // (more than two compared histogram layers + ring 0) take the one-tile kernel for every tile
     const int nw = (allow_stream && n_aux <= 3) ? stream_waves(ctx, a) : 0;
+    if (a.gl_ov && !nw) return hsd_fail(ctx, HSD_ERR_INVALID, "permuted operands need the persistent kernel");
     if (nw) {
         // Whole 128-node tiles of both ranges: the persistent kernel, tiles composed from the ranges' granule lists (a tile on
         // the diagonal of a symmetric region is computed in full and not mirrored: no masks anywhere).  What is left over at
         // the end of a range (< 128 nodes) are strips for the one-tile kernel with its masked stores, in natural order.
         const int64_t i_full = a.i_begin + (a.i_end - a.i_begin) / 128 * 128, j_full = a.j_begin + (a.j_end - a.j_begin) / 128 * 128;
         hsd_ctx::GranList LI{}, LJ{};
-        bool ok = gran_list(ctx, a.i_begin, i_full, stream, &LI);
-        if (ok) { if (a.sym) LJ = LI; else ok = gran_list(ctx, a.j_begin, j_full, stream, &LJ); }
+        bool ok;
+        if (a.gl_ov) {
+            // (the pruned k-nearest sweep: one square region over the permuted operands, its list made by tk_prepare)
+            LI.d_gl = const_cast<int32_t *>(a.gl_ov); LI.d_tmax = const_cast<uint32_t *>(a.tmax_ov); LI.ntiles = a.ntl_ov;
+            LJ = LI;
+            ok = a.sym != 0;
+        } else {
+            ok = gran_list(ctx, a.i_begin, i_full, stream, &LI);
+            if (ok) { if (a.sym) LJ = LI; else ok = gran_list(ctx, a.j_begin, j_full, stream, &LJ); }
+        }
         if (ok) {
             PairArgs b = a;
             b.i_end = i_full; b.j_end = j_full;
@@ -2306,7 +2329,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                 b.gl_i = LI.d_gl; b.gl_j = LJ.d_gl;
                 b.tmax_i = LI.d_tmax; b.tmax_j = LJ.d_tmax;
                 b.ntl_i = LI.ntiles; b.ntl_j = LJ.ntiles;
-                b.suf = ctx->d_suf;
+                b.suf = a.suf ? a.suf : ctx->d_suf;
                 b.stamps = nullptr;
                 if (a.tau) {
                     b.dbg &= ~8;                          // (the lifetime stamps are a matrix-launch hook)
@@ -2321,7 +2344,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     int kept = 0;
                     hipLaunchKernelGGL(tk_tilemax_kernel, dim3((unsigned)a.prune_nt), dim3(64), 0, stream, a.tau16 + a.i_begin, a.prune_nt, ctx->d_tk_tmax);
                     e = hipMemsetAsync(ctx->d_tk_count, 0, sizeof(int), stream);
-                    hipLaunchKernelGGL(tk_filter_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, l_in, n_in, a.prune_lo, a.prune_hi, a.prune_nf,
+                    hipLaunchKernelGGL(tk_filter_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, l_in, n_in, a.prune_lo, a.prune_hi, a.prune_scale, a.prune_nf,
                                        a.prune_nt, ctx->d_tk_tmax, a.prune_drop_band, reinterpret_cast<int2 *>(ctx->d_tk_list), ctx->d_tk_count);
                     if (e == hipSuccess) e = hipMemcpyAsync(&kept, ctx->d_tk_count, sizeof(int), hipMemcpyDeviceToHost, stream);
                     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -3573,6 +3596,124 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
 // The candidate lists hold ORIGINAL node ids (ties are broken by them), the rows are un-permuted at the end: the result is the one the
 // unpruned sweep gives, bit for bit (tests/test_gpu_topk.py).  HSD_TOPK_PRUNE=0 / 1: never / whenever the kind allows.
 // ------------------------------------------------------------------------------------------
+// k-d order of the nodes on nf features F[f][i]: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by
+// node id.  Node-major copy of the features (one node's features in one cache line); once the ranges are short enough their subtrees go to host
+// threads (disjoint ranges of idx: no sharing; a thread that cannot be created leaves its range to the caller, as in hsd_pair_prepare).
+void kd_order_host(const std::vector<double> &F, int64_t n, int nf, std::vector<int32_t> &idx) {
+    idx.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int32_t)i;
+    std::vector<double> A((size_t)n * nf);
+    for (int f = 0; f < nf; ++f)
+        for (int64_t i = 0; i < n; ++i) A[(size_t)i * nf + f] = F[(size_t)f * n + i];
+    const double *Ap = A.data();
+    int32_t *ip = idx.data();
+    const auto split = [Ap, ip, nf](int64_t lo, int64_t hi) -> int64_t {       // returns the split point, or -1 for a leaf
+        if (hi - lo <= 128) return -1;
+        int best = 0;
+        double ext = -1.0;
+        for (int f = 0; f < nf; ++f) {
+            double mn = INFINITY, mx = -INFINITY;
+            for (int64_t q = lo; q < hi; ++q) { const double v = Ap[(size_t)ip[q] * nf + f]; mn = std::min(mn, v); mx = std::max(mx, v); }
+            if (mx - mn > ext) { ext = mx - mn; best = f; }
+        }
+        int64_t mid = lo + ((hi - lo) / 2 + 127) / 128 * 128;
+        if (mid >= hi) mid = lo + (hi - lo) / 2;
+        std::nth_element(ip + lo, ip + mid, ip + hi, [Ap, nf, best](int32_t x, int32_t y) {
+            const double a = Ap[(size_t)x * nf + best], b = Ap[(size_t)y * nf + best];
+            return a < b || (a == b && x < y);
+        });
+        return mid;
+    };
+    const auto subtree = [&split](int64_t lo0, int64_t hi0) noexcept {
+        try {
+            std::vector<std::pair<int64_t, int64_t>> todo{{lo0, hi0}};
+            while (!todo.empty()) {
+                const auto [lo, hi] = todo.back();
+                todo.pop_back();
+                const int64_t mid = split(lo, hi);
+                if (mid < 0) continue;
+                todo.push_back({lo, mid});
+                todo.push_back({mid, hi});
+            }
+        } catch (...) {}                     // (out of memory for the work list: the range stays as it is -- a worse order, the same results)
+    };
+    // the top of the tree on this thread, down to ranges of about n / 16; then one task per range
+    std::vector<std::pair<int64_t, int64_t>> top{{0, n}}, tasks;
+    while (!top.empty()) {
+        const auto [lo, hi] = top.back();
+        top.pop_back();
+        if (hi - lo <= std::max<int64_t>(n / 16, 1024)) { tasks.push_back({lo, hi}); continue; }
+        const int64_t mid = split(lo, hi);
+        if (mid < 0) continue;
+        top.push_back({lo, mid});
+        top.push_back({mid, hi});
+    }
+    const int thr_cap = std::max(1, hsd_hook_int(H_PLAN_THREADS, 16));
+    const int n_thr = std::max(1, std::min<int>(std::min<int>((int)tasks.size(), thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
+    std::atomic<int> next{0};
+    const auto work = [&]() noexcept {
+        for (int t; (t = next.fetch_add(1, std::memory_order_relaxed)) < (int)tasks.size();) subtree(tasks[(size_t)t].first, tasks[(size_t)t].second);
+    };
+    std::vector<std::thread> pool;
+    try {
+        pool.reserve((size_t)n_thr);
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
+    } catch (...) {}
+    work();
+    for (auto &th : pool) th.join();
+}
+
+// zero-pad kinds: F[s][i] = the sum of layer s's bin-form columns of node i = the sum of the ring's member values (|su_i - su_j| <= S_s(i, j))
+template <bool PACK>
+__global__ void tk_feature_seg_kernel(const uint32_t *__restrict__ X, int64_t npad, int64_t n, const HsdSegDesc *__restrict__ tab, double *__restrict__ F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const HsdSegDesc d = tab[blockIdx.y];
+    double t = 0.0;
+    for (int w = 0; w < d.bin_words; ++w) {
+        const uint32_t v = X[(int64_t)(d.bin_col0 + w) * npad + i];
+        t += PACK ? (double)((v & 0xffffu) + (v >> 16)) : (double)v;
+    }
+    F[(int64_t)blockIdx.y * n + i] = t;
+}
+
+// Up[c][p] = U[c][orig[p]] (0 at padding positions), 32-bit words; blockIdx.y = column / row
+__global__ void tk_gather_u32_kernel(const uint32_t *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, uint32_t *__restrict__ Xp) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    const int32_t o = orig[p];
+    const int64_t c = blockIdx.y;
+    Xp[c * npad + p] = o >= 0 ? X[c * npad + o] : 0u;
+}
+
+// members above a layer's threshold per POSITION, recovered from the permuted operands: the non-zero rank values of the stored rank words, and
+// "more than they hold" (any value that sends the planner to the bin form) where the suffix behind the last stored word is not empty
+template <bool PACK>
+__global__ void tk_rnode_kernel(const uint32_t *__restrict__ Xp, const uint32_t *__restrict__ sufp, int64_t npad, const HsdSegDesc *__restrict__ tab,
+                                uint32_t *__restrict__ R) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npad) return;
+    const HsdSegDesc d = tab[blockIdx.y];
+    uint32_t cnt = 0;
+    if (d.rank_col0 >= 0 && d.suf_row0 >= 0) {
+        for (int w = 0; w < d.rank_cap; ++w) {
+            const uint32_t v = Xp[(int64_t)(d.rank_col0 + d.rank_low + w) * npad + p];
+            cnt += PACK ? (uint32_t)((v & 0xffffu) != 0u) + (uint32_t)((v >> 16) != 0u) : (uint32_t)(v != 0u);
+        }
+        if (sufp[(int64_t)(d.suf_row0 + d.rank_cap) * npad + p] > 0u) cnt = PACK ? 2u * (uint32_t)d.rank_cap + 2u : (uint32_t)d.rank_cap + 1u;
+    }
+    R[(int64_t)blockIdx.y * npad + p] = cnt;
+}
+
+// bit 31 of a granule's maximum: one of its 16 positions is too wide for the layer's uint8 range (as hsd_pair_prepare marks them)
+__global__ void tk_wide_kernel(const uint32_t *__restrict__ need, int64_t npad, int ngran16, int best_b, int best_r, uint32_t *__restrict__ g16) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngran16) return;
+    bool wide = false;
+    for (int e = 0; e < 16; ++e) wide = wide || (int)need[(int64_t)16 * g + e] > best_b || (int)need[npad + (int64_t)16 * g + e] > best_r;
+    if (wide) g16[g] |= 0x80000000u;
+}
+
 int tk_prepare(hsd_ctx *ctx) {
     if (ctx->tk_ready) return HSD_OK;
     hsd_tk_release(ctx);                               // (whatever an earlier, failed attempt allocated)
@@ -3587,102 +3728,63 @@ int tk_prepare(hsd_ctx *ctx) {
         t_last = now;
     };
     const int64_t n = ctx->n, npad = ctx->npad;
-    const int cpl = ctx->l1_cols_per_layer, nl = cpl > 0 ? ctx->dcols_alg / cpl : 0;
-    const int G = std::max(1, std::min(8, hsd_hook_int(H_TOPK_GROUPS, 1)));
-    const int nf = nl * G + (ctx->has_point ? 1 : 0);
-    if (nf < 1 || npad % 128 != 0) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: nothing to order the nodes by");
+    const bool seg = ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32;
+    const bool pack = ctx->mode == PAIR_SAD_U16;
+    if (npad % 128 != 0) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: operand stride is no whole number of tiles");
     const int nt = (int)(npad / 128);
-    // features -> host
-    std::vector<double> F((size_t)nf * n);
-    {
+    // bound features V[f][i] with their factors S[f][i] (1 for the raw distance and the ring-0 value; 1 / ring size for a zero-pad layer: the
+    // layer's distance is at least |V_i - V_j| min(S_i, S_j)); the nodes are ordered on V * S
+    int nf = 0, nlay = 0;
+    std::vector<double> V, S;
+    if (!seg) {
+        const int cpl = ctx->l1_cols_per_layer, nl = cpl > 0 ? ctx->dcols_alg / cpl : 0;
+        const int G = std::max(1, std::min(8, hsd_hook_int(H_TOPK_GROUPS, 1)));
+        nlay = nl * G;
+        nf = nlay + (ctx->has_point ? 1 : 0);
+        if (nf < 1) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: nothing to order the nodes by");
+        V.resize((size_t)nf * n);
         DevTmp dF, dP;
-        HSD_TMP_ALLOC(ctx, dF, F.size() * sizeof(double));
-        HSD_TMP_ALLOC(ctx, dP, (size_t)nl * G * TK_SLICES * n * sizeof(double));
-        hipLaunchKernelGGL(tk_feature_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(nl * G * TK_SLICES)), dim3(256), 0, ctx->stream,
-                           (const double *)ctx->d_X, npad, n, cpl, G, dP.as<double>());
-        hipLaunchKernelGGL(tk_feature_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dP.as<double>(), n, nl * G,
+        HSD_TMP_ALLOC(ctx, dF, V.size() * sizeof(double));
+        HSD_TMP_ALLOC(ctx, dP, (size_t)std::max(nlay, 1) * TK_SLICES * n * sizeof(double));
+        if (nlay > 0)
+            hipLaunchKernelGGL(tk_feature_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(nlay * TK_SLICES)), dim3(256), 0, ctx->stream,
+                               (const double *)ctx->d_X, npad, n, cpl, G, dP.as<double>());
+        hipLaunchKernelGGL(tk_feature_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dP.as<double>(), n, nlay,
                            ctx->has_point ? (const double *)ctx->d_H : nullptr, dF.as<double>());
-        HSD_HIP(ctx, hipMemcpyAsync(F.data(), dF.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipMemcpyAsync(V.data(), dF.p, V.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        nlay = ctx->n_seg;
+        nf = nlay + (ctx->has_point ? 1 : 0);
+        if (nlay < 1 || !ctx->d_inv) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: no zero-pad layer to order the nodes by");
+        V.resize((size_t)nf * n);
+        S.assign((size_t)nf * n, 1.0);
+        DevTmp dF;
+        HSD_TMP_ALLOC(ctx, dF, (size_t)nlay * n * sizeof(double));
+        if (pack) hipLaunchKernelGGL(tk_feature_seg_kernel<true>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dF.as<double>());
+        else hipLaunchKernelGGL(tk_feature_seg_kernel<false>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dF.as<double>());
+        HSD_HIP(ctx, hipMemcpyAsync(V.data(), dF.p, (size_t)nlay * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        for (int s2 = 0; s2 < nlay; ++s2)
+            HSD_HIP(ctx, hipMemcpyAsync(S.data() + (size_t)s2 * n, ctx->d_inv + (size_t)s2 * npad, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->has_point) HSD_HIP(ctx, hipMemcpyAsync(V.data() + (size_t)nlay * n, ctx->d_H, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     mark("features (device -> host)");
-    // k-d order: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by node id.  Node-major copy
-    // of the features (one node's features in one cache line); once the ranges are short enough their subtrees go to host threads
-    // (disjoint ranges of idx: no sharing; a thread that cannot be created leaves its range to the caller, as in hsd_pair_prepare).
-    std::vector<int32_t> idx((size_t)n);
-    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int32_t)i;
+    std::vector<int32_t> idx;
     {
-        std::vector<double> A((size_t)n * nf);
-        for (int f = 0; f < nf; ++f)
-            for (int64_t i = 0; i < n; ++i) A[(size_t)i * nf + f] = F[(size_t)f * n + i];
-        const double *Ap = A.data();
-        int32_t *ip = idx.data();
-        const auto split = [Ap, ip, nf](int64_t lo, int64_t hi) -> int64_t {       // returns the split point, or -1 for a leaf
-            if (hi - lo <= 128) return -1;
-            int best = 0;
-            double ext = -1.0;
-            for (int f = 0; f < nf; ++f) {
-                double mn = INFINITY, mx = -INFINITY;
-                for (int64_t q = lo; q < hi; ++q) { const double v = Ap[(size_t)ip[q] * nf + f]; mn = std::min(mn, v); mx = std::max(mx, v); }
-                if (mx - mn > ext) { ext = mx - mn; best = f; }
-            }
-            int64_t mid = lo + ((hi - lo) / 2 + 127) / 128 * 128;
-            if (mid >= hi) mid = lo + (hi - lo) / 2;
-            std::nth_element(ip + lo, ip + mid, ip + hi, [Ap, nf, best](int32_t x, int32_t y) {
-                const double a = Ap[(size_t)x * nf + best], b = Ap[(size_t)y * nf + best];
-                return a < b || (a == b && x < y);
-            });
-            return mid;
-        };
-        const auto subtree = [&split](int64_t lo0, int64_t hi0) noexcept {
-            try {
-                std::vector<std::pair<int64_t, int64_t>> todo{{lo0, hi0}};
-                while (!todo.empty()) {
-                    const auto [lo, hi] = todo.back();
-                    todo.pop_back();
-                    const int64_t mid = split(lo, hi);
-                    if (mid < 0) continue;
-                    todo.push_back({lo, mid});
-                    todo.push_back({mid, hi});
-                }
-            } catch (...) {}                     // (out of memory for the work list: the range stays as it is -- a worse order, the same results)
-        };
-        // the top of the tree on this thread, down to ranges of about n / 16; then one task per range
-        std::vector<std::pair<int64_t, int64_t>> top{{0, n}}, tasks;
-        while (!top.empty()) {
-            const auto [lo, hi] = top.back();
-            top.pop_back();
-            if (hi - lo <= std::max<int64_t>(n / 16, 1024)) { tasks.push_back({lo, hi}); continue; }
-            const int64_t mid = split(lo, hi);
-            if (mid < 0) continue;
-            top.push_back({lo, mid});
-            top.push_back({mid, hi});
-        }
-        const int thr_cap = std::max(1, hsd_hook_int(H_PLAN_THREADS, 16));
-        const int n_thr = std::max(1, std::min<int>(std::min<int>((int)tasks.size(), thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
-        std::atomic<int> next{0};
-        const auto work = [&]() noexcept {
-            for (int t; (t = next.fetch_add(1, std::memory_order_relaxed)) < (int)tasks.size();) subtree(tasks[(size_t)t].first, tasks[(size_t)t].second);
-        };
-        {
-            std::vector<std::thread> pool;
-            try {
-                pool.reserve((size_t)n_thr);
-                for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
-            } catch (...) {}
-            work();
-            for (auto &th : pool) th.join();
-        }
+        std::vector<double> Fo = V;
+        if (seg) for (size_t q = 0; q < Fo.size(); ++q) Fo[q] *= S[q];         // zero-pad layers: the ring's MEAN value
+        kd_order_host(Fo, n, nf, idx);
     }
     mark("k-d order (host)");
     std::vector<int32_t> orig((size_t)npad, -1);
     std::copy(idx.begin(), idx.end(), orig.begin());
-    std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY);
+    std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY), fsc((size_t)nf * nt, INFINITY);
     for (int64_t p = 0; p < n; ++p)
         for (int f = 0; f < nf; ++f) {
-            const double v = F[(size_t)f * n + idx[(size_t)p]];
-            double &a = flo[(size_t)f * nt + p / 128], &b = fhi[(size_t)f * nt + p / 128];
-            a = std::min(a, v); b = std::max(b, v);
+            const size_t src = (size_t)f * n + idx[(size_t)p], dst = (size_t)f * nt + p / 128;
+            flo[dst] = std::min(flo[dst], V[src]); fhi[dst] = std::max(fhi[dst], V[src]);
+            fsc[dst] = std::min(fsc[dst], seg ? S[src] : 1.0);
         }
     const int band_w = std::max(1, std::min(4, hsd_hook_int(H_TOPK_BAND, 1)));      // the first launch: every tile with itself and its band_w successors
     std::vector<int2> band;
@@ -3691,12 +3793,11 @@ int tk_prepare(hsd_ctx *ctx) {
     ctx->tk_band_w = band_w;
     mark("tile intervals + first-launch list");
     int rc;
-    const size_t xcnt = (size_t)std::max(ctx->dcols, 16) * npad;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, xcnt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npad))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, flo.size()))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, fhi.size()))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_scale, fsc.size()))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
     ctx->tk_list_cap = (int)std::min<int64_t>((int64_t)nt * (nt + 1) / 2, 0x7fffffff);
@@ -3706,11 +3807,51 @@ int tk_prepare(hsd_ctx *ctx) {
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_lo, flo.data(), flo.size() * sizeof(double), hipMemcpyHostToDevice));
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_hi, fhi.data(), fhi.size() * sizeof(double), hipMemcpyHostToDevice));
+    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_scale, fsc.data(), fsc.size() * sizeof(double), hipMemcpyHostToDevice));
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(tk_gather_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)std::max(ctx->dcols, 16)), dim3(256), 0, ctx->stream, (const double *)ctx->d_X,
-                       npad, ctx->d_tk_orig, ctx->d_tk_X);
+    const dim3 pgrid((unsigned)((npad + 255) / 256));
     if (ctx->has_point)
-        hipLaunchKernelGGL(tk_gather_kernel, dim3((unsigned)((npad + 255) / 256), 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, ctx->d_tk_H);
+        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, ctx->d_tk_H);
+    if (!seg) {
+        const int cols = std::max(ctx->dcols, 16);
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, (size_t)cols * npad))) return rc;
+        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, ctx->d_tk_orig, ctx->d_tk_X);
+    } else {
+        // the zero-pad kinds' operands: packed words, 1 / ring size per layer, suffix sums -- and, recovered from them, what the tile planner reads:
+        // members above each layer's threshold per position -> maxima per 16-position granule (+ the "too wide for the uint8 range" flags) -> per tile
+        const int cols = std::max(ctx->dcols, 32), ngran16 = (int)(npad / 16);
+        const int64_t sufr = (int64_t)ctx->suf_rows + 1;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_U, (size_t)cols * npad))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_inv, (size_t)nlay * npad))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_suf, (size_t)sufr * npad))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_rmax16, (size_t)nlay * ngran16))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmaxs, (size_t)nlay * nt))) return rc;
+        hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, ctx->d_tk_orig, ctx->d_tk_U);
+        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, (const double *)ctx->d_inv, npad, ctx->d_tk_orig, ctx->d_tk_inv);
+        if (ctx->d_suf) hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)sufr), dim3(256), 0, ctx->stream, ctx->d_suf, npad, ctx->d_tk_orig, ctx->d_tk_suf);
+        else HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_suf, 0, (size_t)sufr * npad * sizeof(uint32_t), ctx->stream));
+        DevTmp dR, dneed;
+        HSD_TMP_ALLOC(ctx, dR, (size_t)nlay * npad * sizeof(uint32_t));
+        HSD_TMP_ALLOC(ctx, dneed, (size_t)2 * npad * sizeof(uint32_t));
+        if (pack) hipLaunchKernelGGL(tk_rnode_kernel<true>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npad, ctx->d_seg_tab, dR.as<uint32_t>());
+        else hipLaunchKernelGGL(tk_rnode_kernel<false>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npad, ctx->d_seg_tab, dR.as<uint32_t>());
+        hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, dR.as<uint32_t>(), npad, ngran16, ctx->d_tk_rmax16);
+        for (int s2 = 0; s2 < nlay && pack; ++s2) {
+            const HsdSegDesc &d = ctx->seg_tab[s2];
+            if (d.r8_col0 < 0) continue;
+            HSD_HIP(ctx, hipMemsetAsync(dneed.p, 0, (size_t)2 * npad * sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(u8_need_kernel, dim3(pgrid.x), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_tk_U, npad, npad, d, dneed.as<uint32_t>());
+            hipLaunchKernelGGL(tk_wide_kernel, dim3((unsigned)((ngran16 + 255) / 256)), dim3(256), 0, ctx->stream, dneed.as<uint32_t>(), npad, ngran16, d.r8_k16 - d.r8_r16, d.r8_r16,
+                               ctx->d_tk_rmax16 + (size_t)s2 * ngran16);
+        }
+        std::vector<int32_t> gl((size_t)ngran16);
+        for (int g = 0; g < ngran16; ++g) gl[(size_t)g] = g;
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_tk_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)(((int64_t)nt * nlay + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_gl, nt, ctx->d_tk_rmax16, ngran16, nlay,
+                           ctx->d_tk_tmaxs);
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (gl, the temporaries)
+    }
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     mark("allocations + permuted operands");
     ctx->tk_nf = nf; ctx->tk_nt = nt;
@@ -3722,10 +3863,11 @@ int tk_prepare(hsd_ctx *ctx) {
 int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *done) {
     *done = false;
     const int64_t n = ctx->n, npad = ctx->npad;
+    const bool seg = ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32;
     PairArgs a{};
     a.npad = npad;
     a.dcols = ctx->dcols;
-    a.n_seg = 0;
+    a.n_seg = seg ? ctx->n_seg : 0;
     a.list_cap = ctx->list_cap;
     a.dcols_valid = ctx->dcols_alg;
     { const char *e = hsd_hook(H_TOPK_DEBUG); a.dbg = e ? atoi(e) : 0; }
@@ -3733,13 +3875,25 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     a.i_begin = 0; a.i_end = npad; a.j_begin = 0; a.j_end = npad;
     a.sym = 1; a.mirror = 1;
     {
+        // the persistent kernel must take the region (its LDS budget: at most three per-node vectors)
+        if (a.n_seg + (ctx->has_point ? 1 : 0) > 3) return HSD_OK;
         PairArgs probe = a;
         probe.tau = reinterpret_cast<const double *>(ctx);          // (any non-null value: the k-nearest kernels have no output alignment to check)
         if (!stream_waves(ctx, probe)) return HSD_OK;
     }
     int rc = tk_prepare(ctx);
     if (rc) return rc;
-    a.X = a.Y = ctx->d_tk_X;
+    if (seg) {
+        a.X = a.Y = ctx->d_tk_U;
+        a.inv = ctx->d_tk_inv;
+        a.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
+        a.rmax = ctx->d_rmax;
+        a.ngran = ctx->ngran;
+        a.suf = ctx->d_tk_suf;
+        a.gl_ov = ctx->d_tk_gl; a.tmax_ov = ctx->d_tk_tmaxs; a.ntl_ov = ctx->tk_nt;
+    } else {
+        a.X = a.Y = ctx->d_tk_X;
+    }
     a.point = ctx->has_point ? ctx->d_tk_H : nullptr;
     a.orig_of = ctx->d_tk_orig;
     const int64_t rows = npad;
@@ -3749,6 +3903,8 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     const size_t oTau = carve((size_t)rows * sizeof(double)), oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
     const size_t oVal = carve((size_t)rows * cap * sizeof(double)), oOi = carve((size_t)rows * k * sizeof(int)), oOv = carve((size_t)rows * k * sizeof(double));
     const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64), oFi = carve((size_t)n * k * sizeof(int)), oFv = carve((size_t)n * k * sizeof(double));
+    const int64_t M = std::min<int64_t>(n, 1024), ldS = (M + 127) / 128 * 128;
+    const size_t oS = carve((size_t)n * ldS * sizeof(double)), oTn = carve((size_t)n * sizeof(double));
     if (ctx->scratch_bytes < off) {
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -3764,7 +3920,41 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     int *d_fidx = reinterpret_cast<int *>(base + oFi);
     HSD_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)rows * sizeof(int), ctx->stream));
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_tau, rows, (double)INFINITY);
+    // First thresholds, part one: the k-th smallest of 1 024 columns spread evenly over the NATURAL node order (the unpruned sweep's own first
+    // thresholds, computed on the untouched operands).  A row unlike everything near it in the k-d order -- a hub, whose distances to the
+    // thousands of leaves crowd just above its k-th -- would otherwise start from a threshold that admits most of the graph (zero-pad distance,
+    // BA N = 100k: lists of 38 000 entries).  Part two, the tiles next to a row's own, only tightens it.  The raw fp64 distance starts from
+    // +inf: its lists stay short without the sample (longest 709 of 2 048 at BA N = 100k, 27 000 soak calls), which would cost it 4.4 ms
+    // of arithmetic + 0.8 GB of sample matrix per call (66.7 -> 74.4 ms, measured).
+    if (!seg) hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_tau, rows, (double)INFINITY);
+    else {
+        double *d_S = reinterpret_cast<double *>(base + oS), *d_tauN = reinterpret_cast<double *>(base + oTn);
+        PairArgs nat{};
+        nat.X = ctx->d_X; nat.Y = ctx->d_X;
+        nat.inv = ctx->d_inv;
+        nat.point = ctx->has_point ? ctx->d_H : nullptr;
+        nat.npad = npad; nat.dcols = ctx->dcols; nat.n_seg = ctx->n_seg;
+        nat.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
+        nat.rmax = ctx->d_rmax; nat.ngran = ctx->ngran; nat.list_cap = ctx->list_cap;
+        nat.dcols_valid = ctx->dcols_alg;
+        nat.rbase = 0; nat.i_begin = 0; nat.i_end = n;
+        const int n_sub = (int)((M + 127) / 128);
+        const int64_t n_tiles_total = (n + 127) / 128;
+        for (int t = 0; t < n_sub; ++t) {
+            const int64_t tile = n_sub >= n_tiles_total ? t : (int64_t)t * n_tiles_total / n_sub;
+            PairArgs sub = nat;
+            sub.j_begin = tile * 128;
+            sub.j_end = std::min<int64_t>(n, sub.j_begin + 128);
+            sub.out = d_S + (int64_t)t * 128 - sub.j_begin;
+            sub.ld = ldS;
+            if ((rc = launch_region(ctx, sub, tile_edge(ctx), ctx->stream))) return rc;
+            if (sub.j_end - sub.j_begin < 128)
+                hipLaunchKernelGGL(fill_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_S, ldS, n, (int)(t * 128 + (sub.j_end - sub.j_begin)),
+                                   (int)((t + 1) * 128), (double)INFINITY);
+        }
+        hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, n_sub * 128, (int64_t)0, n, k, 0.0, d_tauN);
+        hipLaunchKernelGGL(tk_permute_tau_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig, rows, d_tauN, d_tau);
+    }
     PairArgs b = a;
     b.tau = d_tau; b.cand_cnt = d_cnt; b.cand_idx = d_idx; b.cand_val = d_val; b.cand_cap = (int)cap;
     b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16);
@@ -3776,7 +3966,7 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
     // the rest of the pair space in anti-diagonal phases, each filtered against the thresholds of the moment (tightened after phases 1, 2, 4)
     b.explicit_tiles = nullptr; b.n_explicit = 0;
-    b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = ctx->tk_band_w;
+    b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_scale = seg ? ctx->d_tk_scale : nullptr; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = ctx->tk_band_w;
     // (measured at BA N = 100k: 2 phases overflow the lists -- the band thresholds meet half the columns at once --, 3 / 4 / 5 / 6 / 8 / 12 / 16 take
     //  66.3 / 65.7 / 65.6 / 66.8 / 68.8 / 72.1 / 74.5 ms with longest lists of 847 / 690 / 296 / 360 / 709 entries; twice the nodes, twice the appends per phase)
     int n_phases = ctx->tk_nt <= 1200 ? 5 : 8;
@@ -3825,7 +4015,11 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     {
         // raw fp64 W1 over the whole graph: the pruned sweep on node-permuted operands (above) where it applies
         const int pr = hsd_hook_int(H_TOPK_PRUNE, -1);
-        if (ctx->mode == PAIR_L1_F64 && r0 == 0 && r1 == n && k <= 128 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0 && !hsd_hook(H_TOPK_GEOM)) {
+        // (the zero-pad kinds only on request, HSD_TOPK_PRUNE=1: their whole unpruned call takes 20 ms at BA N = 100k, half of which the one-time setup
+        //  of the pruned sweep costs -- it pays from the second call of a prepared distance on)
+        const bool l1 = ctx->mode == PAIR_L1_F64 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0;
+        const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && pr == 1;
+        if ((l1 || zp) && r0 == 0 && r1 == n && k <= 128 && !hsd_hook(H_TOPK_GEOM)) {
             bool done = false;
             const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);
             if (rcp != HSD_OK || done) return rcp;

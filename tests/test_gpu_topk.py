@@ -250,12 +250,16 @@ def test_pruned_sweep_small_and_ragged(engine, n, k):
         g = barabasi_albert(n, 3, 5)
     engine.set_graph(g.rowptr, g.col)
     engine.signature_build_degree(2)
-    engine.pair_prepare(0, 0, 0, 2)
-    D = engine.pair_rows_host()
-    ridx, rval = _reference_topk(D, k)
-    with _env(HSD_STREAM=1, HSD_TOPK_PRUNE=1):
-        idx, val = engine.pair_topk(k)
-    assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
+    # the raw fp64 distance (pruned by default where the persistent kernel runs) and the zero-pad distance (pruned on request), packed and plain words
+    for mode, extra in (((0, 0, 0, 2), {}), ((0, 1, 0, 1), {}), ((0, 1, 0, 1), {"HSD_SAD16": 0})):
+        with _env(**extra):
+            engine.pair_prepare(*mode)
+            D = engine.pair_rows_host()
+        ridx, rval = _reference_topk(D, k)
+        with _env(HSD_STREAM=1, HSD_TOPK_PRUNE=1, **extra):
+            engine.pair_prepare(*mode)
+            idx, val = engine.pair_topk(k)
+        assert np.array_equal(val, rval) and np.array_equal(idx, ridx), (mode, extra)
 
 
 def test_pruned_sweep_falls_back_when_a_list_overflows(engine, capfd):
@@ -277,3 +281,23 @@ def test_pruned_sweep_falls_back_when_a_list_overflows(engine, capfd):
     assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
     if "overflow 1" in log:
         assert "attempt 0" in log                            # the unpruned sweep ran after it
+
+
+def test_pruned_sweep_of_the_zero_pad_distance_on_request(engine, capfd):
+    """HSD_TOPK_PRUNE=1 extends the pruned sweep to the zero-pad distance (Variant B): a permuted copy of the packed words, the layers' 1 / ring
+    sizes, the suffix sums and -- recovered from those -- the per-granule maxima the tile planner reads; bound = gap of the rings' value sums over
+    the larger ring; first thresholds from the column sample AND the neighbouring tiles.  Same lists as the unpruned sweep, tile pairs dropped."""
+    from hsd_amd.graph import barabasi_albert
+    n, k = 24000 + 19, 20
+    g = barabasi_albert(n, 5, 23)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 1, 0, 2)
+    ridx, rval = engine.pair_topk(k)                         # default: unpruned for this kind
+    with _env(HSD_TOPK_PRUNE=1, HSD_TOPK_VERBOSE=1):
+        capfd.readouterr()
+        idx, val = engine.pair_topk(k)
+        log = capfd.readouterr().err
+    kept = [tuple(int(x) for x in ln.split(":")[1].split("tile")[0].split("of")) for ln in log.splitlines() if "pruned launch" in ln]
+    assert kept and sum(a for a, b in kept) < 0.9 * sum(b for a, b in kept) and "overflow 0" in log, log[-500:]
+    assert np.array_equal(val, rval) and np.array_equal(idx, ridx)

@@ -1,22 +1,23 @@
 """dev: the pruned k-nearest sweep (raw fp64 W1 on node-permuted operands) against the unpruned one: same result, time of a warm call.
-usage: topk_prune_ab.py [n=100000] [k=20]"""
+usage: topk_prune_ab.py [n=100000] [k=20] [variant=A|B]   (B: the zero-pad distance, pruned only on request)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hsd_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+MODE = (0, 1, 0, 2) if (len(sys.argv) > 3 and sys.argv[3] == "B") else (0, 0, 0, 3)
 g = hsd_amd.barabasi_albert(n, 5, 42)
 eng = hsd_amd.Engine(0)
 eng.set_graph(g.rowptr, g.col)
 eng.signature_build_degree(3)
-eng.pair_prepare(0, 0, 0, 3)
+eng.pair_prepare(*MODE)
 res = {}
 cases = [("0", "1")] + [("1", g) for g in os.environ.get("AB_GROUPS", "1").split(",")]
 for prune, groups in cases:
     os.environ["HSD_TOPK_PRUNE"] = prune
     os.environ["HSD_TOPK_GROUPS"] = groups
-    eng.pair_prepare(0, 0, 0, 3)                      # (the permuted operands are rebuilt with the operands)
+    eng.pair_prepare(*MODE)                           # (the permuted operands are rebuilt with the operands)
     ts = []
     for rep in range(3):
         if rep == 2: os.environ["HSD_TOPK_VERBOSE"] = "1"
