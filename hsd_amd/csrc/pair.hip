@@ -26,7 +26,9 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <system_error>
 #include <thread>
 #include <type_traits>
@@ -3637,22 +3639,39 @@ void kd_order_host(const std::vector<double> &F, int64_t n, int nf, std::vector<
             }
         } catch (...) {}                     // (out of memory for the work list: the range stays as it is -- a worse order, the same results)
     };
-    // the top of the tree on this thread, down to ranges of about n / 16; then one task per range
-    std::vector<std::pair<int64_t, int64_t>> top{{0, n}}, tasks;
-    while (!top.empty()) {
-        const auto [lo, hi] = top.back();
-        top.pop_back();
-        if (hi - lo <= std::max<int64_t>(n / 16, 1024)) { tasks.push_back({lo, hi}); continue; }
-        const int64_t mid = split(lo, hi);
-        if (mid < 0) continue;
-        top.push_back({lo, mid});
-        top.push_back({mid, hi});
-    }
+    // A shared work list: a range longer than 4 096 nodes is split by whoever takes it and its halves go back on the list; shorter ones are finished
+    // on the spot.  (Splitting the top of the tree on one thread first -- four full passes over the nodes -- took 7 of the 10 ms of the setup.)
     const int thr_cap = std::max(1, hsd_hook_int(H_PLAN_THREADS, 16));
-    const int n_thr = std::max(1, std::min<int>(std::min<int>((int)tasks.size(), thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
-    std::atomic<int> next{0};
+    const int n_thr = std::max(1, std::min<int>(thr_cap, std::max(1, (int)std::thread::hardware_concurrency())));
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<int64_t, int64_t>> list{{0, n}};
+    int busy = 0;                                    // ranges taken and not yet finished (their halves may still arrive)
     const auto work = [&]() noexcept {
-        for (int t; (t = next.fetch_add(1, std::memory_order_relaxed)) < (int)tasks.size();) subtree(tasks[(size_t)t].first, tasks[(size_t)t].second);
+        for (;;) {
+            std::pair<int64_t, int64_t> r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !list.empty() || busy == 0; });
+                if (list.empty()) return;            // nothing listed, nobody splitting: done
+                r = list.back();
+                list.pop_back();
+                ++busy;
+            }
+            if (r.second - r.first <= 4096) subtree(r.first, r.second);
+            else {
+                const int64_t mid = split(r.first, r.second);
+                if (mid >= 0) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    try { list.push_back({r.first, mid}); list.push_back({mid, r.second}); } catch (...) {}      // (no memory: a worse order, the same results)
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                --busy;
+            }
+            cv.notify_all();
+        }
     };
     std::vector<std::thread> pool;
     try {
@@ -4015,10 +4034,10 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     {
         // raw fp64 W1 over the whole graph: the pruned sweep on node-permuted operands (above) where it applies
         const int pr = hsd_hook_int(H_TOPK_PRUNE, -1);
-        // (the zero-pad kinds only on request, HSD_TOPK_PRUNE=1: their whole unpruned call takes 20 ms at BA N = 100k, half of which the one-time setup
-        //  of the pruned sweep costs -- it pays from the second call of a prepared distance on)
+        // (the zero-pad kinds from ~100k nodes on, or on request: below that their whole unpruned call is shorter than the pruned sweep's one-time setup
+        //  + call -- BA N = 60k: 10.3 ms against 12.3 for a first call, 6.9 for every later one; N = 100k: 21.5-22 against 21.0 / 12.2; N = 200k: 73 against 50.6 / 33.4)
         const bool l1 = ctx->mode == PAIR_L1_F64 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0;
-        const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && pr == 1;
+        const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && (pr == 1 || (pr != 0 && ctx->npad / 128 >= 780));
         if ((l1 || zp) && r0 == 0 && r1 == n && k <= 128 && !hsd_hook(H_TOPK_GEOM)) {
             bool done = false;
             const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);

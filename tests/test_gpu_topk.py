@@ -103,15 +103,30 @@ def test_topk_phased_sweep_on_the_persistent_kernel(engine, mode, k, phases):
         assert np.array_equal(val2, rval[a:b])
 
 
-def test_topk_target_size_without_the_matrix(engine):
-    """BA N = 100 000 (the target graph), zero-pad W1, 20 nearest: the phased sweep against rows of the full matrix."""
+def test_topk_target_size_without_the_matrix(engine, capfd):
+    """BA N = 100 000 (the target graph), zero-pad W1, 20 nearest: the default call -- from ~100k nodes on the PRUNED sweep on node-permuted operands --
+    against rows of the full matrix, and against the unpruned phased sweep (HSD_TOPK_PRUNE=0), list for list."""
+    import os
     from hsd_amd.graph import barabasi_albert
     n, k = 100000, 20
     g = barabasi_albert(n, 5, 42)
     engine.set_graph(g.rowptr, g.col)
     engine.signature_build_degree(3)
     engine.pair_prepare(0, 1, 0, 2)
-    idx, val = engine.pair_topk(k)
+    os.environ["HSD_TOPK_VERBOSE"] = "1"
+    try:
+        capfd.readouterr()
+        idx, val = engine.pair_topk(k)
+        log = capfd.readouterr().err
+    finally:
+        os.environ.pop("HSD_TOPK_VERBOSE", None)
+    assert "pruned launch" in log and "overflow 0" in log, log[-400:]
+    os.environ["HSD_TOPK_PRUNE"] = "0"
+    try:
+        uidx, uval = engine.pair_topk(k)
+    finally:
+        os.environ.pop("HSD_TOPK_PRUNE", None)
+    assert np.array_equal(uidx, idx) and np.array_equal(uval, val)
     M = engine.pair_rows_device()
     try:
         for r in (0, 1, 127, 128, 4097, n // 2, n - 1):
