@@ -3598,6 +3598,8 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
 // The candidate lists hold ORIGINAL node ids (ties are broken by them), the rows are un-permuted at the end: the result is the one the
 // unpruned sweep gives, bit for bit (tests/test_gpu_topk.py).  HSD_TOPK_PRUNE=0 / 1: never / whenever the kind allows.
 // ------------------------------------------------------------------------------------------
+namespace {
+
 // k-d order of the nodes on nf features F[f][i]: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by
 // node id.  Node-major copy of the features (one node's features in one cache line); once the ranges are short enough their subtrees go to host
 // threads (disjoint ranges of idx: no sharing; a thread that cannot be created leaves its range to the caller, as in hsd_pair_prepare).
@@ -4018,6 +4020,8 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     *done = true;
     return HSD_OK;
 }
+
+}  // namespace
 
 extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out) try {
     HSD_CHECK_CTX(ctx);
