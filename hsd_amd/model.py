@@ -368,6 +368,17 @@ class MultiHSD(HSD):
             out.extend([np.sum(coeffs), np.mean(coeffs)] if len(coeffs) > 0 else [0.0, 0.0])
         return out
 
+    def get_layer_sum(self, wavelets: np.ndarray, node) -> list:
+        """model/multiscale_HSD.py:64-73 for one node of a host wavelet matrix: the sum of every ring's coefficients
+        (the reference keeps it beside get_triple; its callers there are commented out)."""
+        i = self.node2idx[node]
+        out = [0] * (self.hop + 1)
+        for hop, level in enumerate(self.hierarchy[node]):
+            for u in level:
+                if u != '':
+                    out[hop] += wavelets[i, self.node2idx[u]]
+        return out
+
     def parallel_embed(self, n_workers=1, approx=True) -> dict:
         """model/multiscale_HSD.py:76-98; one GPU pass per scale replaces the pool."""
         self.embeddings = self._embed(approx)
