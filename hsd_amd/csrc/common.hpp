@@ -252,6 +252,7 @@ bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop, int n_bins);
 void hsd_khop_ms_release(hsd_ctx *ctx);
 void hsd_release_operands(hsd_ctx *ctx);
 void hsd_tk_release(hsd_ctx *ctx);
+int hsd_tk_order_device(hsd_ctx *ctx, const double *d_F, int64_t n, int nf, int32_t *d_order);      // csrc/tkorder.hip
 extern "C" void hsd_heat_release_internal(hsd_ctx *ctx);
 int hsd_launch_pair_rowquirk_tiled(hsd_ctx *ctx, const double *psi_dev, int64_t ldpsi, int64_t r0, int64_t r1, double *dst, int64_t dld);
 int hsd_launch_pair_ragged_tiled(hsd_ctx *ctx, int layer_lo, int layer_hi, int64_t r0, int64_t r1, double *dst, int64_t dld);

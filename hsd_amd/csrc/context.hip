@@ -55,6 +55,7 @@ const HsdHookInfo hsd_hook_table[H_COUNT] = {
     {"HSD_TOPK_PRUNE", "fused k-nearest consumer over the whole graph: 0 = never the pruned sweep on node-permuted operands; 1 = whenever the kind allows (default: the raw fp64 distance where the persistent kernel runs, the zero-pad distance from ~100k nodes on)"},
     {"HSD_TOPK_GROUPS", "pruned k-nearest sweep: column groups per layer in the lower bound (1..8, default 1); read when the permuted operands are built"},
     {"HSD_TOPK_BAND", "pruned k-nearest sweep: the first launch evaluates every tile against itself and this many successors in the node order (1..4, default 1); read when the permuted operands are built"},
+    {"HSD_TOPK_ORDER", "pruned k-nearest sweep: 0 = the node order from host threads instead of from the device (csrc/tkorder.hip); read when the permuted operands are built"},
     {"HSD_TOPK_PHASES", "fused k-nearest consumer: number of equal phases of the sweep"},
     {"HSD_TOPK_GEOM", "fused k-nearest consumer: 0 | 1 = never / always the geometric launch schedule"},
     {"HSD_TOPK_CAP", "fused k-nearest consumer: capacity of a row's candidate list (overflow -> retry path)"},

@@ -43,6 +43,7 @@ enum HsdHook {
     H_TOPK_PRUNE,
     H_TOPK_GROUPS,
     H_TOPK_BAND,
+    H_TOPK_ORDER,
     H_TOPK_PHASES,
     H_TOPK_GEOM,
     H_TOPK_CAP,

@@ -3735,6 +3735,41 @@ __global__ void tk_wide_kernel(const uint32_t *__restrict__ need, int64_t npad, 
     if (wide) g16[g] |= 0x80000000u;
 }
 
+// Fo[f][i] = V[f][i] x the layer's factor (1 / ring size; 1 for the ring-0 value): what the nodes are ordered on
+__global__ void tk_scale_features_kernel(const double *__restrict__ V, const double *__restrict__ inv, int64_t npad, int64_t n, int n_scaled, double *__restrict__ Fo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = blockIdx.y;
+    const double v = V[(int64_t)f * n + i];
+    Fo[(int64_t)f * n + i] = f < n_scaled ? v * inv[(int64_t)f * npad + i] : v;
+}
+
+// per tile of the node order and feature: [min, max] of V over the tile's nodes and their smallest factor (+inf / -inf / +inf for a tile of padding only);
+// 128 threads = one tile, blockIdx.y = feature
+__global__ void tk_tile_interval_kernel(const double *__restrict__ V, const double *__restrict__ inv, int64_t npad, int64_t n, int n_scaled, const int32_t *__restrict__ orig,
+                                        int nt, double *__restrict__ lo, double *__restrict__ hi, double *__restrict__ sc) {
+    __shared__ double part[3][2];
+    const int t = blockIdx.x, f = blockIdx.y;
+    const int32_t o = orig[(int64_t)t * 128 + threadIdx.x];
+    double mn = INFINITY, mx = -INFINITY, s = INFINITY;
+    if (o >= 0) {
+        mn = mx = V[(int64_t)f * n + o];
+        s = f < n_scaled ? inv[(int64_t)f * npad + o] : 1.0;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, d, 64));
+        mx = fmax(mx, __shfl_xor(mx, d, 64));
+        s = fmin(s, __shfl_xor(s, d, 64));
+    }
+    if ((threadIdx.x & 63u) == 0u) { part[0][threadIdx.x >> 6] = mn; part[1][threadIdx.x >> 6] = mx; part[2][threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo[(int64_t)f * nt + t] = fmin(part[0][0], part[0][1]);
+        hi[(int64_t)f * nt + t] = fmax(part[1][0], part[1][1]);
+        sc[(int64_t)f * nt + t] = fmin(part[2][0], part[2][1]);
+    }
+}
+
 int tk_prepare(hsd_ctx *ctx) {
     if (ctx->tk_ready) return HSD_OK;
     hsd_tk_release(ctx);                               // (whatever an earlier, failed attempt allocated)
@@ -3756,79 +3791,101 @@ int tk_prepare(hsd_ctx *ctx) {
     // bound features V[f][i] with their factors S[f][i] (1 for the raw distance and the ring-0 value; 1 / ring size for a zero-pad layer: the
     // layer's distance is at least |V_i - V_j| min(S_i, S_j)); the nodes are ordered on V * S
     int nf = 0, nlay = 0;
-    std::vector<double> V, S;
+    std::vector<double> V, S;                          // (host copies: only for the host order, HSD_TOPK_ORDER=0)
+    DevTmp dV;                                         // the features on the device, nf rows of n; the zero-pad layers' factors are ctx->d_inv's rows
+    const bool dev_order = hsd_hook_int(H_TOPK_ORDER, 1) != 0;
     if (!seg) {
         const int cpl = ctx->l1_cols_per_layer, nl = cpl > 0 ? ctx->dcols_alg / cpl : 0;
         const int G = std::max(1, std::min(8, hsd_hook_int(H_TOPK_GROUPS, 1)));
         nlay = nl * G;
         nf = nlay + (ctx->has_point ? 1 : 0);
         if (nf < 1) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: nothing to order the nodes by");
-        V.resize((size_t)nf * n);
-        DevTmp dF, dP;
-        HSD_TMP_ALLOC(ctx, dF, V.size() * sizeof(double));
+        DevTmp dP;
+        HSD_TMP_ALLOC(ctx, dV, (size_t)nf * n * sizeof(double));
         HSD_TMP_ALLOC(ctx, dP, (size_t)std::max(nlay, 1) * TK_SLICES * n * sizeof(double));
         if (nlay > 0)
             hipLaunchKernelGGL(tk_feature_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(nlay * TK_SLICES)), dim3(256), 0, ctx->stream,
                                (const double *)ctx->d_X, npad, n, cpl, G, dP.as<double>());
         hipLaunchKernelGGL(tk_feature_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dP.as<double>(), n, nlay,
-                           ctx->has_point ? (const double *)ctx->d_H : nullptr, dF.as<double>());
-        HSD_HIP(ctx, hipMemcpyAsync(V.data(), dF.p, V.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                           ctx->has_point ? (const double *)ctx->d_H : nullptr, dV.as<double>());
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (dP goes)
     } else {
         nlay = ctx->n_seg;
         nf = nlay + (ctx->has_point ? 1 : 0);
         if (nlay < 1 || !ctx->d_inv) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: no zero-pad layer to order the nodes by");
+        HSD_TMP_ALLOC(ctx, dV, (size_t)nf * n * sizeof(double));
+        if (pack) hipLaunchKernelGGL(tk_feature_seg_kernel<true>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dV.as<double>());
+        else hipLaunchKernelGGL(tk_feature_seg_kernel<false>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dV.as<double>());
+        if (ctx->has_point)
+            HSD_HIP(ctx, hipMemcpyAsync(dV.as<double>() + (size_t)nlay * n, ctx->d_H, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (!dev_order) {
         V.resize((size_t)nf * n);
-        S.assign((size_t)nf * n, 1.0);
-        DevTmp dF;
-        HSD_TMP_ALLOC(ctx, dF, (size_t)nlay * n * sizeof(double));
-        if (pack) hipLaunchKernelGGL(tk_feature_seg_kernel<true>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dF.as<double>());
-        else hipLaunchKernelGGL(tk_feature_seg_kernel<false>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dF.as<double>());
-        HSD_HIP(ctx, hipMemcpyAsync(V.data(), dF.p, (size_t)nlay * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        for (int s2 = 0; s2 < nlay; ++s2)
-            HSD_HIP(ctx, hipMemcpyAsync(S.data() + (size_t)s2 * n, ctx->d_inv + (size_t)s2 * npad, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->has_point) HSD_HIP(ctx, hipMemcpyAsync(V.data() + (size_t)nlay * n, ctx->d_H, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipMemcpyAsync(V.data(), dV.p, V.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (seg) {
+            S.assign((size_t)nf * n, 1.0);
+            for (int s2 = 0; s2 < nlay; ++s2)
+                HSD_HIP(ctx, hipMemcpyAsync(S.data() + (size_t)s2 * n, ctx->d_inv + (size_t)s2 * npad, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    mark("features (device -> host)");
-    std::vector<int32_t> idx;
-    {
-        std::vector<double> Fo = V;
-        if (seg) for (size_t q = 0; q < Fo.size(); ++q) Fo[q] *= S[q];         // zero-pad layers: the ring's MEAN value
-        kd_order_host(Fo, n, nf, idx);
-    }
-    mark("k-d order (host)");
-    std::vector<int32_t> orig((size_t)npad, -1);
-    std::copy(idx.begin(), idx.end(), orig.begin());
-    std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY), fsc((size_t)nf * nt, INFINITY);
-    for (int64_t p = 0; p < n; ++p)
-        for (int f = 0; f < nf; ++f) {
-            const size_t src = (size_t)f * n + idx[(size_t)p], dst = (size_t)f * nt + p / 128;
-            flo[dst] = std::min(flo[dst], V[src]); fhi[dst] = std::max(fhi[dst], V[src]);
-            fsc[dst] = std::min(fsc[dst], seg ? S[src] : 1.0);
+    mark("features");
+    int rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, (size_t)nf * nt))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, (size_t)nf * nt))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_scale, (size_t)nf * nt))) return rc;
+    if (dev_order) {
+        // the order on the device (csrc/tkorder.hip), on V x factor (zero-pad layers: the ring's MEAN value); then every tile's feature intervals
+        DevTmp dFo;
+        const double *Fo = dV.as<double>();
+        if (seg) {
+            HSD_TMP_ALLOC(ctx, dFo, (size_t)nf * n * sizeof(double));
+            hipLaunchKernelGGL(tk_scale_features_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, dV.as<double>(), (const double *)ctx->d_inv,
+                               npad, n, nlay, dFo.as<double>());
+            Fo = dFo.as<double>();
         }
+        HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_orig, 0xff, (size_t)npad * sizeof(int32_t), ctx->stream));          // padding positions: -1
+        if ((rc = hsd_tk_order_device(ctx, Fo, n, nf, ctx->d_tk_orig))) return rc;
+        mark("k-d order (device)");
+        hipLaunchKernelGGL(tk_tile_interval_kernel, dim3((unsigned)nt, (unsigned)nf), dim3(128), 0, ctx->stream, dV.as<double>(), seg ? (const double *)ctx->d_inv : nullptr,
+                           npad, n, seg ? nlay : 0, (const int32_t *)ctx->d_tk_orig, nt, ctx->d_tk_lo, ctx->d_tk_hi, ctx->d_tk_scale);
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (dFo goes)
+    } else {
+        std::vector<int32_t> idx;
+        {
+            std::vector<double> Fo = V;
+            if (seg) for (size_t q = 0; q < Fo.size(); ++q) Fo[q] *= S[q];
+            kd_order_host(Fo, n, nf, idx);
+        }
+        mark("k-d order (host)");
+        std::vector<int32_t> orig((size_t)npad, -1);
+        std::copy(idx.begin(), idx.end(), orig.begin());
+        std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY), fsc((size_t)nf * nt, INFINITY);
+        for (int64_t p = 0; p < n; ++p)
+            for (int f = 0; f < nf; ++f) {
+                const size_t src = (size_t)f * n + idx[(size_t)p], dst = (size_t)f * nt + p / 128;
+                flo[dst] = std::min(flo[dst], V[src]); fhi[dst] = std::max(fhi[dst], V[src]);
+                fsc[dst] = std::min(fsc[dst], seg ? S[src] : 1.0);
+            }
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_lo, flo.data(), flo.size() * sizeof(double), hipMemcpyHostToDevice));
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_hi, fhi.data(), fhi.size() * sizeof(double), hipMemcpyHostToDevice));
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_scale, fsc.data(), fsc.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     const int band_w = std::max(1, std::min(4, hsd_hook_int(H_TOPK_BAND, 1)));      // the first launch: every tile with itself and its band_w successors
     std::vector<int2> band;
     for (int t = 0; t < nt; ++t)
         for (int d = 0; d <= band_w && t + d < nt; ++d) band.push_back(make_int2(t, t + d));
     ctx->tk_band_w = band_w;
     mark("tile intervals + first-launch list");
-    int rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npad))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, flo.size()))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, fhi.size()))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_scale, fsc.size()))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
     ctx->tk_list_cap = (int)std::min<int64_t>((int64_t)nt * (nt + 1) / 2, 0x7fffffff);
     HSD_HIP(ctx, hipMalloc(&ctx->d_tk_list, (size_t)ctx->tk_list_cap * sizeof(int2)));
     HSD_HIP(ctx, hipMalloc(&ctx->d_tk_band, band.size() * sizeof(int2)));
     ctx->tk_band_n = (int)band.size();
-    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_lo, flo.data(), flo.size() * sizeof(double), hipMemcpyHostToDevice));
-    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_hi, fhi.data(), fhi.size() * sizeof(double), hipMemcpyHostToDevice));
-    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_scale, fsc.data(), fsc.size() * sizeof(double), hipMemcpyHostToDevice));
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
     const dim3 pgrid((unsigned)((npad + 255) / 256));
     if (ctx->has_point)

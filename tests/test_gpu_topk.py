@@ -277,6 +277,34 @@ def test_pruned_sweep_small_and_ragged(engine, n, k):
         assert np.array_equal(val, rval) and np.array_equal(idx, ridx), (mode, extra)
 
 
+@pytest.mark.parametrize("mode", [(0, 0, 0, 3), (0, 1, 0, 2)], ids=["raw-fp64", "zero-pad"])
+def test_pruned_sweep_node_order_from_the_device_and_from_the_host(engine, capfd, mode):
+    """The node order of the pruned sweep is built on the device (csrc/tkorder.hip: per level of the k-d tree extents, keys, one radix sort);
+    HSD_TOPK_ORDER=0 keeps the host threads' order.  Any order gives the same lists; the device's must prune about as well as the host's
+    (its keys carry 44 bits of a value, ties stay in the order they had)."""
+    from hsd_amd.graph import barabasi_albert
+    n, k = 24000 + 77, 20
+    g = barabasi_albert(n, 5, 31)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    got = {}
+    for order in (0, 1):
+        with _env(HSD_TOPK_PRUNE=1, HSD_TOPK_ORDER=order, HSD_TOPK_VERBOSE=1):
+            engine.pair_prepare(*mode)                        # (the permuted operands go with the operands)
+            capfd.readouterr()
+            idx, val = engine.pair_topk(k)
+            log = capfd.readouterr().err
+        kept = [tuple(int(x) for x in ln.split(":")[1].split("tile")[0].split("of")) for ln in log.splitlines() if "pruned launch" in ln]
+        assert kept and "overflow 0" in log, log[-500:]
+        assert ("k-d order (device)" in log) == (order == 1) and ("k-d order (host)" in log) == (order == 0), log[:800]
+        got[order] = (idx, val, sum(a for a, b in kept) / sum(b for a, b in kept))
+    with _env(HSD_TOPK_PRUNE=0):
+        ridx, rval = engine.pair_topk(k)
+    for order in (0, 1):
+        assert np.array_equal(got[order][0], ridx) and np.array_equal(got[order][1], rval), order
+    assert got[1][2] < 1.15 * got[0][2] + 0.02, (got[0][2], got[1][2])
+
+
 def test_pruned_sweep_falls_back_when_a_list_overflows(engine, capfd):
     """A node order that does not fit the distance (eight column groups per layer as features: HSD_TOPK_GROUPS=8) leaves loose first thresholds and
     overflowing lists on a scale-free graph: the call must notice, hand over to the unpruned sweep and still return the exact result."""
