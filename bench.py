@@ -523,7 +523,7 @@ def fused_knn(eng, mat, n, k):
     extra = {}
     if os.environ.get("HSD_TOPK_PRUNE") is None:
         # the same call with the pruning switched off (every tile pair evaluated): what the pruned sweep on node-permuted operands saves, and that both give
-        # the same lists.  (Default: pruned for the raw fp64 distance where the persistent kernel runs and for the zero-pad distance from ~60k nodes on.)
+        # the same lists.  (Default: pruned for the raw fp64 distance where the persistent kernel runs and for the zero-pad distance from ~50k nodes on.)
         os.environ["HSD_TOPK_PRUNE"] = "0"
         try:
             eng.pair_topk(k)

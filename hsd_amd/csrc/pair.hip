@@ -4095,12 +4095,12 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     {
         // raw fp64 W1 over the whole graph: the pruned sweep on node-permuted operands (above) where it applies
         const int pr = hsd_hook_int(H_TOPK_PRUNE, -1);
-        // (the zero-pad kinds from ~60k nodes on, or on request: the smallest size at which a FIRST call -- one-time setup included -- was measured
-        //  ahead of the unpruned call.  BA N = 60k: 10.2 ms unpruned against 8.0 for a first call, 6.1 for every later one; N = 100k: 20.0-20.9 against
-        //  15.4 / 12.0; N = 200k: 73 against 33.4 for a later call.  With the node order from host threads (HSD_TOPK_ORDER=0) the first calls were
+        // (the zero-pad kinds from ~50k nodes (384 tiles) on, or on request: where a FIRST call -- one-time setup included -- is ahead of the unpruned
+        //  call.  BA N = 40k: 5.05 ms unpruned against 5.2-5.3 for a first call, 4.1 for every later one; N = 60k: 9.1-9.6 against 7.5-7.8 / 6.1;
+        //  N = 80k: 13.8-14.6 against 10.8-11.5 / 8.8; N = 100k: 20.0-20.9 against 15.4 / 12.0; N = 200k: 73 against 33.4 for a later call.  With the node order from host threads (HSD_TOPK_ORDER=0) the first calls were
         //  12.4-13.0 and 20.9-21.5 ms and the default began at 100k nodes.)
         const bool l1 = ctx->mode == PAIR_L1_F64 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0;
-        const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && (pr == 1 || (pr != 0 && ctx->npad / 128 >= 468));
+        const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && (pr == 1 || (pr != 0 && ctx->npad / 128 >= 384));
         if ((l1 || zp) && r0 == 0 && r1 == n && k <= 128 && !hsd_hook(H_TOPK_GEOM)) {
             bool done = false;
             const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);

@@ -104,7 +104,7 @@ def test_topk_phased_sweep_on_the_persistent_kernel(engine, mode, k, phases):
 
 
 def test_topk_target_size_without_the_matrix(engine, capfd):
-    """BA N = 100 000 (the target graph), zero-pad W1, 20 nearest: the default call -- from ~60k nodes on the PRUNED sweep on node-permuted operands --
+    """BA N = 100 000 (the target graph), zero-pad W1, 20 nearest: the default call -- from ~50k nodes on the PRUNED sweep on node-permuted operands --
     against rows of the full matrix, and against the unpruned phased sweep (HSD_TOPK_PRUNE=0), list for list."""
     import os
     from hsd_amd.graph import barabasi_albert
