@@ -55,8 +55,10 @@ class Graph:
         a = np.concatenate([src, dst[~loops]])
         b = np.concatenate([dst, src[~loops]])
         ww = np.concatenate([w, w[~loops]])
-        # later duplicates win (networkx overwrites edge data): stable sort, keep last
-        order = np.arange(a.shape[0])
+        # later duplicates win (networkx overwrites edge data), whichever orientation they were given in: both directed copies of
+        # an edge carry the position of the edge in the input; sort by (key, position), keep the last of every key
+        pos = np.arange(src.shape[0])
+        order = np.concatenate([pos, pos[~loops]])
         key = a * n + b
         perm = np.lexsort((order, key))
         key_s = key[perm]
@@ -148,6 +150,8 @@ def read_edgelist(path, nodetype=str):
     idx = {}
     nodes = []
     src, dst, w = [], [], []
+    seen = {}                  # weight an edge holds so far: a repeated line WITHOUT a weight column leaves it alone (networkx updates the
+                               # edge's data with an empty dict), one with a weight overwrites it
     with open(path, "r", encoding="utf-8") as fin:
         for line in fin:
             p = line.find("#")
@@ -163,7 +167,12 @@ def read_edgelist(path, nodetype=str):
                     nodes.append(x)
             src.append(idx[u])
             dst.append(idx[v])
-            w.append(float(s[2]) if len(s) > 2 else 1.0)
+            key = (idx[u], idx[v]) if idx[u] <= idx[v] else (idx[v], idx[u])
+            if len(s) > 2:
+                seen[key] = float(s[2])
+            else:
+                seen.setdefault(key, 1.0)
+            w.append(seen[key])
     return Graph.from_edges(nodes, src, dst, w)
 
 
