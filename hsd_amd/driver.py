@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .formats import read_label
+from .formats import read_label, save_edgelist
 from .graph import Graph, read_edgelist
 from .model import HSD, MultiHSD
 
@@ -50,16 +50,30 @@ def laplacian_extreme_eigenvalues(g: Graph):
     return float(next((e for e in low if e > 0.001), low[-1])), top
 
 
-def filter_distance_matrix(dist_mat, nodes: list, ratio=0.05) -> list:
-    """tools/util.py:133-159: the (int(#pairs * ratio) + 1) pairs i < j with the LARGEST distance,
-    sorted descending (stable), as (node_i, node_j, distance)."""
+def filter_edgelist(edgelist: list, save_path=None, ratio=0.05) -> list:
+    """tools/util.py:133-144: the int(len * ratio) + 1 heaviest edges (u, v, weight), heaviest first, equal weights in the order
+    they came in; the caller's list is sorted in place, as there; written as an edgelist when `save_path` is given."""
+    edgelist.sort(key=lambda e: e[2], reverse=True)
+    kept = edgelist[:int(len(edgelist) * ratio) + 1]
+    if save_path is not None:
+        save_edgelist(save_path, kept)
+    return kept
+
+
+def filter_distance_matrix(dist_mat, nodes: list, save_path=None, ratio=0.05) -> list:
+    """tools/util.py:147-159 (same positional order: matrix, nodes, save_path, ratio): the (int(#pairs * ratio) + 1) pairs i < j with
+    the LARGEST distance, sorted descending (stable), as (node_i, node_j, distance); saved as `u v d` lines when `save_path` is given."""
     dist_mat = np.asarray(dist_mat)
-    assert dist_mat.shape[0] == dist_mat.shape[1] == len(nodes)
+    assert dist_mat.shape[0] == dist_mat.shape[1], "the distance matrix must be square"
+    assert dist_mat.shape[0] == len(nodes), "one row of the distance matrix per node"
     iu, ju = np.triu_indices(len(nodes), 1)
     d = dist_mat[iu, ju]
     keep = int(len(d) * ratio) + 1
     order = np.argsort(-d, kind="stable")[:keep]
-    return [(nodes[iu[t]], nodes[ju[t]], float(d[t])) for t in order]
+    kept = [(nodes[iu[t]], nodes[ju[t]], float(d[t])) for t in order]
+    if save_path is not None:
+        save_edgelist(save_path, kept)
+    return kept
 
 
 def _knn_score(dists, labels, cv, n_neighbor):

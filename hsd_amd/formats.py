@@ -62,7 +62,7 @@ def save_vectors(nodes: list, vectors: list, path: str):
     """tools/rw.py:13-22 (pandas to_csv(header=False, float_format='%.8f'))."""
     with open(path, "w", encoding="utf-8") as f:
         for n, v in zip(nodes, vectors):
-            f.write(",".join([str(n)] + ["%.8f" % float(x) for x in v]) + "\n")
+            f.write(",".join([str(n)] + ["" if x != x else "%.8f" % float(x) for x in v]) + "\n")       # (NaN: an empty field, as pandas writes it)
 
 
 def save_vectors_dict(vectors: dict, path: str):
@@ -95,15 +95,24 @@ def save_distance_edgelist(path: str, nodes: list, mat):
 
 
 def read_distance(path: str, n_nodes: int) -> np.ndarray:
-    """tools/rw.py:50-65 (node labels are integer indices)."""
+    """tools/rw.py:50-65 (node labels are integer indices).  Every line up to the end of the file must be `u v d` separated by single
+    blanks: a blank line is a ValueError there (it reads to EOF and unpacks three fields), and so it is here."""
     mat = np.zeros((n_nodes, n_nodes), dtype=float)
     with open(path, mode="r", encoding="utf-8") as fin:
         for line in fin:
-            if not line.strip():
-                break
             u, v, dist = line.strip().split(" ")
             mat[int(u), int(v)] = mat[int(v), int(u)] = float(dist)
     return mat
+
+
+def save_edgelist(path: str, edgelist: list):
+    """tools/rw.py:101-116: `u v` or `u v w` per edge; tuples shorter than two are skipped, longer than three leave an empty line."""
+    with open(path, mode="w+", encoding="utf-8") as fout:
+        for edge in edgelist:
+            if len(edge) < 2:
+                continue
+            text = f"{edge[0]} {edge[1]}" if len(edge) == 2 else f"{edge[0]} {edge[1]} {edge[2]}" if len(edge) == 3 else ""
+            fout.write(f"{text}\n")
 
 
 # ---- labels -----------------------------------------------------------------------------------

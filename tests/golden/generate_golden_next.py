@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Golden vectors for the rows SURVEY.md 8(f) marks "next": SIR influence labels, the `.layers`
 hierarchy file format, the embeddings CSV / distance edgelist formats, and the scale sweep of the
-driver.  RUN ONLY IN THE BUILD CONTAINER (imports the reference); writes next_rows.json."""
+driver.  RUN ONLY IN THE BUILD CONTAINER (imports the reference); writes next_rows.json.
+(The member order inside a ring of the `.layers` text is the iteration order of a Python set of strings, tools/hierarchy.py:33-35, i.e. it
+changes from run to run with the interpreter's hash seed; the committed `layers` section is one such run -- the tests compare the reader on
+that text and the writer ring by ring as sets.  Every other section is reproduced bit for bit.)"""
 import contextlib
 import io
 import json
@@ -98,6 +101,34 @@ def main():
     np.fill_diagonal(Dm, 0.0)
     kept = ref_util.filter_distance_matrix(Dm, [str(i) for i in range(12)], None, 0.05)
     out["filter"] = {"D": Dm.tolist(), "kept": [[a, b, float(c)] for a, b, c in kept]}
+    # the same with tied distances (a descending sort that keeps equal entries in row-major order), a save path (tools/rw.py:101-116) and
+    # the in-place behaviour of filter_edgelist (tools/util.py:133-144)
+    Dt = np.round(rng.random((9, 9)) * 4) / 4
+    Dt = np.maximum(Dt, Dt.T)
+    np.fill_diagonal(Dt, 0.0)
+    names = [f"v{i}" for i in range(9)]
+    with tempfile.TemporaryDirectory() as d:
+        sp = os.path.join(d, "kept.edgelist")
+        kept_t = ref_util.filter_distance_matrix(Dt, names, sp, 0.3)
+        text = open(sp).read()
+    edges = [("a", "b", 0.5), ("c", "d", 2.0), ("e", "f", 0.5), ("g", "h", 2.0), ("i", "j", 1.0), ("k", "l", 0.25), ("m", "n", 2.0)]
+    edges_in = [list(e) for e in edges]
+    edges_kept = ref_util.filter_edgelist(edges, None, 0.3)
+    out["filter_saved"] = {"D": Dt.tolist(), "nodes": names, "ratio": 0.3, "kept": [[a, b, float(c)] for a, b, c in kept_t], "text": text,
+                           "edges_in": edges_in, "edges_kept": [list(e) for e in edges_kept], "edges_sorted_in_place": [list(e) for e in edges]}
+    # embeddings with a missing value (pandas writes an empty field) and a distance file with a blank line (a ValueError in read_distance)
+    with tempfile.TemporaryDirectory() as d:
+        pv = os.path.join(d, "nan.csv")
+        ref_rw.save_vectors(["5", "6"], [[1.0, float("nan"), 2.5], [0.125, 3.0, float("nan")]], pv)
+        nan_text = open(pv).read()
+        pd_ = os.path.join(d, "blank.edgelist")
+        open(pd_, "w").write("0 1 0.5\n\n1 2 0.25\n")
+        try:
+            ref_rw.read_distance(pd_, 3)
+            blank = "no error"
+        except Exception as e:                          # noqa: BLE001
+            blank = type(e).__name__
+    out["rw_edge_cases"] = {"nan_vectors_text": nan_text, "read_distance_blank_line": blank}
 
     with open(os.path.join(HERE, "next_rows.json"), "w") as f:
         json.dump(out, f)

@@ -40,9 +40,19 @@ def test_vectors_csv_and_distance_edgelist(tmp_path):
     assert np.array_equal(formats.read_distance(str(p2), 4), np.asarray(r["read_distance"]))
     assert formats.read_label(os.path.join(GOLDEN, "graphs", "barbell.label"))["1"] >= 0
     assert formats.read_label(str(tmp_path / "none.label")) == {}
+    # a missing value is an empty field (pandas), a blank line in a distance file is the reference's ValueError
+    e = G["rw_edge_cases"]
+    pn = tmp_path / "nan.csv"
+    formats.save_vectors(["5", "6"], [[1.0, float("nan"), 2.5], [0.125, 3.0, float("nan")]], str(pn))
+    assert pn.read_text() == e["nan_vectors_text"]
+    pb = tmp_path / "blank.edgelist"
+    pb.write_text("0 1 0.5\n\n1 2 0.25\n")
+    assert e["read_distance_blank_line"] == "ValueError"
+    with pytest.raises(ValueError):
+        formats.read_distance(str(pb), 3)
 
 
-def test_scale_range_and_filter():
+def test_scale_range_and_filter(tmp_path):
     from hsd_amd import driver
     for name, rec in G["driver"].items():
         g = load_graph(name)
@@ -53,8 +63,17 @@ def test_scale_range_and_filter():
         lam = np.linalg.eigvalsh(g.laplacian_dense())
         assert driver.recommend_scale_range(list(lam)) == (rec["scale_min"], rec["scale_max"])
     D = np.asarray(G["filter"]["D"])
-    kept = driver.filter_distance_matrix(D, [str(i) for i in range(12)], 0.05)
+    kept = driver.filter_distance_matrix(D, [str(i) for i in range(12)], None, 0.05)         # (the reference's positional order)
     assert [[a, b, c] for a, b, c in kept] == G["filter"]["kept"]
+    # with ties (equal distances keep their row-major order under the descending sort) and saved as an edgelist (tools/rw.py:101-116)
+    rec = G["filter_saved"]
+    Dt = np.asarray(rec["D"])
+    p = tmp_path / "kept.edgelist"
+    kept = driver.filter_distance_matrix(Dt, rec["nodes"], str(p), rec["ratio"])
+    assert [[a, b, c] for a, b, c in kept] == rec["kept"] and p.read_text() == rec["text"]
+    edges = [tuple(e) for e in rec["edges_in"]]
+    assert [list(e) for e in driver.filter_edgelist(edges, None, rec["ratio"])] == rec["edges_kept"]
+    assert [list(e) for e in edges] == rec["edges_sorted_in_place"]
 
 
 # ---------------------------------------------------------------- GPU
