@@ -37,6 +37,23 @@ def get_hierarchical_representation(graph, maxHop, engine=None):
     return out
 
 
+def get_node_hierarchical_structure(graph, node, maxHop: int, engine=None):
+    """tools/hierarchy.py:25-38 for ONE node: [[node], ring 1, ..., ring maxHop] (always maxHop + 1 lists, empty once the component
+    is exhausted), one k-hop sweep from that source on the device; members in ascending index order."""
+    g = Graph.coerce(graph)
+    eng = _engine(engine)
+    eng.set_graph(g.rowptr, g.col)
+    i = g.node2idx[node]
+    offsets, members = eng.khop_members(maxHop, i, i + 1)
+    return [[g.nodes[u] for u in members[offsets[k]:offsets[k + 1]]] for k in range(maxHop + 1)]
+
+
+def build_node_idx_map(graph):
+    """tools/util.py:11-24: (idx2node, node2idx) in the graph's node order -- the row / column order of every matrix."""
+    g = Graph.coerce(graph)
+    return {i: v for i, v in enumerate(g.nodes)}, dict(g.node2idx)
+
+
 _SUPPORTED = ['l1', 'l2', 'kl', 'symmetric_kl', 'js', 'wasserstein_guass', 'wasserstein', 'hellinger']
 _CODE = {"wasserstein": L.METRIC_WASSERSTEIN, "kl": L.METRIC_KL, "symmetric_kl": L.METRIC_SYMMETRIC_KL}
 
@@ -54,3 +71,7 @@ def calculate_distance(p, q, metric, engine=None):
 
 
 metrics = types.SimpleNamespace(calculate_distance=calculate_distance)
+
+# the rest of what `from tools import *` gives a caller of the reference on this path (tools/__init__.py:2-4: hierarchy.*, util.*)
+from .formats import read_hierarchy, read_label, save_hierarchical_representation          # noqa: E402,F401
+from .driver import filter_distance_matrix, filter_edgelist, recommend_scale_range, scale_boundary      # noqa: E402,F401

@@ -93,3 +93,21 @@ def test_bench_line_contract(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and isinstance(c["sample"], str)
     assert d["parity"]["ok"] is True and d["parity"]["tol"] == 1e-6
+
+
+def test_single_node_structure_and_index_maps(engine, capsys):
+    """tools.get_node_hierarchical_structure (tools/hierarchy.py:25-38) is one row of get_hierarchical_representation -- always maxHop + 1
+    lists, empty ones once the component is exhausted -- and build_node_idx_map (tools/util.py:11-24) follows the node order of the matrices."""
+    from hsd_amd import tools
+    g = load_graph("karate")
+    full = tools.get_hierarchical_representation(g, 3, engine=engine)
+    capsys.readouterr()
+    for v in (g.nodes[0], g.nodes[7], g.nodes[-1]):
+        one = tools.get_node_hierarchical_structure(g, v, 3, engine=engine)
+        assert one == full[v] and one[0] == [v] and len(one) == 4
+    line = load_graph("line")
+    far = tools.get_node_hierarchical_structure(line, line.nodes[0], line.n_node + 2, engine=engine)
+    assert len(far) == line.n_node + 3 and sum(len(r) for r in far) == line.n_node and far[-1] == []
+    idx2node, node2idx = tools.build_node_idx_map(g)
+    assert [idx2node[i] for i in range(g.n_node)] == g.nodes and all(node2idx[v] == i for i, v in enumerate(g.nodes))
+    assert tools.scale_boundary(1.0, 4.0) == (-np.log(0.95) / 2.0, -np.log(0.85) / 2.0)
