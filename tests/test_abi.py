@@ -23,6 +23,16 @@ def test_header_symbols_exported():
         assert hasattr(lib, name), f"{name} declared in include/hsd.h but not exported"
     # the binding table covers the header exactly
     assert sorted(_lib.SIGNATURES) == names
+    # ... and the dynamic symbol table holds nothing but the library's own hsd_* names (csrc/libhsd_amd.map): no C++ internals, no kernel
+    # stubs, none of the rocprim templates tkorder.hip instantiates -- nothing a host application's own copies could collide with
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm:
+        out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+        assert exported and all(e.startswith("hsd_") for e in exported), [e for e in exported if not e.startswith("hsd_")][:5]
+        assert set(names) <= set(exported) and len(exported) <= len(names) + 4, sorted(set(exported) - set(names))
 
 
 def test_loader_sets_prototypes_and_version():
