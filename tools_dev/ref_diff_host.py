@@ -1,6 +1,7 @@
 """dev, BUILD CONTAINER ONLY (imports /root/reference): randomized differential run of the host-only helpers against the reference's own
 functions -- `.layers` reader, label reader, embeddings CSV writer / reader, distance edgelist writer, scale range, edge filter -- results AND
-exceptions must agree.  The graph container is compared with networkx itself in tests/test_graph_cpu.py.  usage: python3 tools_dev/ref_diff_host.py [seed]"""
+exceptions must agree; and the SIR labels' host arithmetic (hsd_amd/sir.py: ring sizes x decay weights, the class cut) against tools/SIR.py's per-origin
+infection loop on random graphs, with the ring sizes of this tool taken from the CPU oracle in place of hsd_khop_sizes (the GPU test uses the real call).  The graph container is compared with networkx itself in tests/test_graph_cpu.py.  usage: python3 tools_dev/ref_diff_host.py [seed]"""
 import contextlib
 import io
 import os
@@ -18,8 +19,18 @@ sys.modules.setdefault("pygsp", types.ModuleType("pygsp"))
 np.float = float                                    # the reference predates numpy 1.24
 
 with contextlib.redirect_stdout(io.StringIO()):
-    from tools import dataloader as r_dl, hierarchy as r_h, rw as r_rw, util as r_util      # noqa: E402
-from hsd_amd import driver, formats                                                          # noqa: E402
+    from tools import SIR as r_sir, dataloader as r_dl, hierarchy as r_h, rw as r_rw, util as r_util      # noqa: E402
+from hsd_amd import driver, formats, sir                                                     # noqa: E402
+from oracle import hsd_oracle as orc                                                         # noqa: E402  (a dev tool may)
+
+
+class OracleSizes:
+    """Stands in for the Engine in THIS TOOL ONLY: ring sizes from the CPU oracle, so that sir.py's arithmetic can be compared without a GPU."""
+    def set_graph(self, rowptr, col):
+        self.rowptr, self.col = rowptr, col
+
+    def khop_sizes(self, hop):
+        return np.array([[len(r) for r in row] for row in orc.khop_rings(self.rowptr, self.col, hop)], dtype=np.int32)
 
 
 def outcome(fn, *a):
@@ -91,6 +102,21 @@ def main(seed):
             a, b = r_util.filter_distance_matrix(D, names, sp1, ratio), driver.filter_distance_matrix(D, names, sp2, ratio)
             if [tuple(x) for x in a] != [tuple(x) for x in b] or open(sp1).read() != open(sp2).read():
                 bad.append(("filter_distance_matrix", n, ratio))
+    import networkx as nx
+    for _ in range(150):                             # SIR influence and labels
+        n = int(nrng.integers(5, 60))
+        G = nx.gnp_random_graph(n, float(nrng.choice([1.5 / n, 3 / n, 0.3])), seed=int(nrng.integers(1 << 30)))
+        G = nx.relabel_nodes(G, {i: str(i) for i in G})
+        if G.number_of_edges() == 0:
+            continue
+        t, ncls = int(nrng.integers(1, 8)), int(nrng.integers(2, 6))
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ref = r_sir.SIR(G, 1.0, t)
+            ref.start()
+        mine = sir.SIR(G, 1.0, t, engine=OracleSizes())
+        mine.start()
+        if ref.label_nodes(ncls) != mine.label_nodes(ncls) or any(abs(mine.influence[v] - ref.influence[v]) > 1e-12 * max(1.0, ref.influence[v]) for v in G):
+            bad.append(("SIR", n, t, ncls))
     for b in bad[:10]:
         print("MISMATCH", b)
     print(f"ref_diff_host: seed {seed}, {len(bad)} mismatches")
