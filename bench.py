@@ -83,6 +83,7 @@ def parse():
                          "'none' to skip.  Default: extra,2,3,4,5 at --gpus 1, 4 at --gpus 8, none otherwise")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the scipy baseline sample of the headline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--detail", default=None, help="file name of the detail record (default bench_detail.json, next to bench.py and under gpurun_out/)")
     ap.add_argument("--weak", action="store_true", help="round-1 weak-scaling mode: ER N = nodes * sqrt(P), per-GPU output fixed")
     # overrides (measurement scripts): a custom graph instead of a named workload
     ap.add_argument("--graph", default=None, choices=["er", "ba"])
@@ -410,16 +411,18 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
             # the bit-parallel sweep does not expand one BFS per source: its bytes are the frontier rows it gathers and the
             # planes it streams, (hop - 1) pulls per batch of 4096 sources, 512 B per CSR entry and 4 x 512 B per vertex
             moved = (hop - 1) * (float(g.rowptr[-1]) + 4.0 * n) * 512.0 * ((r1 - r0 + 4095) // 4096)
-            # priced by SURVEY 8(d)'s ALGORITHMIC bytes (one BFS expansion per source + the histogram rows); what the sweep
-            # itself moves (frontier planes) is the secondary figure
+            # priced by the bytes of THIS algorithm (the frontier planes it streams).  SURVEY 8(d)'s per-source figure (one BFS expansion
+            # per source) describes a different algorithm: the bit-parallel sweep advances 4096 sources per gathered row, so that figure
+            # divided by the time can exceed the HBM peak -- kept only as a labelled equivalent, never as a fraction
+            sec = sweep_ms * 1e-3
             sweep = {"kernel": "ms_pull / ms_hist kernels (bit-parallel k-hop sweep, 4096 sources per batch, + per-hop histograms)",
-                     "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
-                     "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
-                     "frac_of_hbm": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "bytes_moved": moved, "moved_GBps": round(moved / (sweep_ms * 1e-3) / 1e9, 1),
-                     "moved_frac_of_hbm": round(moved / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "bound": "row gathers out of the Infinity Cache (about 8.6 TB/s, MI355X_MICROARCH.md): bytes_moved, the planes the "
-                              "bit-parallel sweep actually streams, is 3-4x the algorithmic bytes of one BFS per source"}
+                     "ms": round(sweep_ms, 4), "bytes_alg": moved,
+                     "bytes_alg_is": "(hop - 1) x (nnz + 4 n) x 512 B per batch of 4096 sources: the frontier planes gathered and streamed",
+                     "achieved_GBps": round(moved / sec / 1e9, 1), "frac_of_hbm": round(moved / sec / 1e9 / HBM_PEAK_GBS, 4),
+                     "per_source_bfs_equivalent": {"bytes": bytes_sweep, "GBps": round(bytes_sweep / sec / 1e9, 1),
+                                                   "note": "SURVEY 8(d): sum over sources of sum_{v in ball_{K-1}} (8 + 4 deg v) + histogram rows -- the bytes "
+                                                           "one BFS per source would move; not this kernel's traffic, so no fraction of the HBM peak is quoted"},
+                     "bound": "row gathers out of the Infinity Cache (about 8.6 TB/s, MI355X_MICROARCH.md)"}
         else:
             sweep = {"kernel": "khop_kernel (per-source k-hop sweep + per-hop histograms)", "ms": round(sweep_ms, 4), "bytes_alg": bytes_sweep,
                      "achieved_GBps": round(bytes_sweep / (sweep_ms * 1e-3) / 1e9, 1),
@@ -819,6 +822,131 @@ def run_config5(eng, cpu_seconds):
 
 
 # ------------------------------------------------------------------------------------------------
+# output: ONE compact contract line on stdout; every other figure goes to bench_detail.json (+ stderr)
+# ------------------------------------------------------------------------------------------------
+METRIC = "node-pairs/sec on NxN structural-distance matrix"
+LINE_LIMIT = 4000               # bytes of the contract line (the driver keeps only a tail of stdout: a 20 KB line was lost in round 4)
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_bytes_alg", "kernel_ms", "bytes_alg", "valu_frac", "limiter")
+# row blocks hold full rows: a pair (i, j) with i and j on different ranks is evaluated by both, so P ranks can at best
+# reach P / (2 - 1/P) of one GPU's rate before any communication (3.6 at P = 4 ... 4.27 at P = 8; measured 4.3-4.8 per-block on one GPU
+# because small blocks also skip the mirrored stores' tail); DESIGN.md section 5 C1
+def row_block_ceiling(world):
+    return round(world / (2.0 - 1.0 / world), 2)
+
+
+def _short(text, limit):
+    text = str(text)
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def _config_summary(c):
+    """One number per side configuration: config, value, unit, ms_per_step, frac (+ parity.ok, error)."""
+    if "error" in c and "value" not in c and "variants" not in c:
+        return dict(config=c.get("config"), error=_short(c["error"], 120))
+    out = dict(config=c.get("config"))
+    src = c
+    if "variants" in c:                                    # degree workloads list both variants: variant B (main.py's call) is the figure
+        vs = [v for v in c["variants"] if "error" not in v]
+        src = next((v for v in vs if v.get("variant") == "B"), vs[0] if vs else {"error": c["variants"][0].get("error")})
+        out["variant"] = src.get("variant")
+    if "error" in src:
+        return dict(out, error=_short(src["error"], 120))
+    out.update(value=src.get("value"), unit=_short(src.get("unit", ""), 40))
+    ms = src.get("ms_per_step", src.get("ms_end_to_end"))
+    if ms is None and "seconds" in src:
+        ms = src["seconds"] * 1e3
+    out["ms_per_step"] = ms
+    rf = src.get("roofline") or {}
+    out["frac"] = rf.get("frac")
+    if rf.get("traffic_over_bytes_alg") is not None:
+        out["traffic_over_bytes_alg"] = rf["traffic_over_bytes_alg"]
+    par = src.get("parity") or c.get("parity")
+    if par:
+        out["parity_ok"] = par.get("ok")
+    if "exact" in src:
+        out["exact"] = src["exact"]
+    return out
+
+
+def compact_line(d, detail_path):
+    """The contract line: the keys the driver reads, the roofline / cpu_baseline / parity objects with scalar fields only, one
+    summary per side configuration; < LINE_LIMIT bytes whatever the run measured (optional keys are dropped first)."""
+    cfg = d["config"]
+    line = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype")}
+    line["data"] = _short(d["data"], 100)
+    line["config"] = dict(workload=_short(cfg.get("workload_short") or cfg["workload"], 240), nodes=cfg["nodes"], edges=cfg["edges"], hop=cfg["hop"], bins=cfg["bins"],
+                          parallelism=_short(cfg["parallelism"], 80))
+    line["roofline"] = {k: d["roofline"].get(k) for k in ROOFLINE_KEYS}
+    cb = d.get("cpu_baseline")
+    line["cpu_baseline"] = dict(value=cb["value"], unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], sample=_short(cb["sample"], 330)) if cb else None
+    line["parity"] = d.get("parity")
+    if d["n_gpus"] > 1:
+        line["kernel_ms_per_rank"] = d.get("kernel_ms_per_rank")
+        ph = d.get("phases_s") or {}
+        line["phases_s"] = dict(khop_signature_build=ph.get("khop_signature_build"), allgather=ph.get("allgather"), exchange=_short(ph.get("exchange", ""), 90))
+        line["design_ceiling"] = dict(speedup_at_most=row_block_ceiling(d["n_gpus"]),
+                                      why="full rows per rank: each off-diagonal pair is evaluated on two ranks")
+    optional = []
+    pool = d.get("cpu_baseline_pool")
+    if pool:
+        line["cpu_baseline_pool"] = dict(value=pool["value"], unit=pool["unit"], cores=pool["cores"], kind=pool["kind"])
+        optional.append("cpu_baseline_pool")
+    sec = d.get("secondary")
+    if sec:
+        line["secondary"] = _config_summary(dict(sec, config="variant " + str(sec.get("variant"))))
+        optional.append("secondary")
+    knn = d.get("fused_knn")
+    if knn:
+        line["fused_knn"] = dict(k=knn.get("k"), ms_end_to_end=knn.get("ms_end_to_end"), exact=knn.get("exact"))
+        optional.append("fused_knn")
+    line["configs"] = [_config_summary(c) for c in d.get("configs") or []]
+    line["device"] = d.get("device")
+    line["detail"] = detail_path
+    for key in optional + ["configs"]:
+        if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT:
+            break
+        line.pop(key, None)
+    return line
+
+
+def _strict(obj):
+    """NaN / inf have no JSON spelling: a figure that came out non-finite is reported as null."""
+    if isinstance(obj, float):
+        return obj if math.isfinite(obj) else None
+    if isinstance(obj, dict):
+        return {str(k): _strict(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_strict(v) for v in obj]
+    if isinstance(obj, (np.floating, np.integer)):
+        return _strict(obj.item())
+    return obj
+
+
+def emit(detail, detail_name=None):
+    """bench_detail.json (next to bench.py, and under gpurun_out/ so it travels back from a GPU box) gets everything measured;
+    stdout gets exactly ONE line, the compact contract line, last."""
+    detail = _strict(detail)
+    name = detail_name or "bench_detail.json"
+    text = json.dumps(detail, indent=1, allow_nan=False)
+    written = None
+    for folder in (REPO, os.path.join(REPO, "gpurun_out")):
+        try:
+            if os.path.isdir(folder):
+                with open(os.path.join(folder, name), "w") as f:
+                    f.write(text + "\n")
+                written = written or name
+        except OSError:
+            pass
+    print("bench detail (also in %s):" % (written or "no file: directory not writable"), file=sys.stderr)
+    print(json.dumps(detail, allow_nan=False), file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(detail, written), allow_nan=False)
+    assert len(line) < LINE_LIMIT and "\n" not in line
+    sys.stdout.flush()
+    print(line, flush=True)
+    return line
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -826,14 +954,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    dist = None
-    if world > 1:
-        # control plane only (unique-id broadcast, barriers, max over ranks); the data-plane
-        # exchange is the library's own ncclAllGather over RCCL
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    rk = Ranks(dist, rank, world)
 
     import hsd_amd
 
@@ -867,15 +987,24 @@ def main():
         cfg_list = "none" if custom or args.workload != "target" else ("extra,2,3,4,5" if world == 1 else ("4" if world == 8 else "none"))
     cfgs = [] if cfg_list == "none" else [c.strip() for c in cfg_list.split(",") if c.strip()]
 
-    # ---- CPU baseline first (rank 0, single GPU only): the process pool forks, which must happen
-    # before anything initialises the GPU in this process ----
+    # ---- CPU baseline first, on rank 0 of ANY world size (the other ranks wait in the rendezvous below): the process pool
+    # forks, which must happen before anything initialises the GPU -- or starts gloo's threads -- in this process ----
     cpu = None
     cpu_pool = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0 and wass:
+    if rank == 0 and args.cpu_seconds > 0 and wass:
         cpu = {primary_v: scipy_baseline(g, spec["hop"], primary_v, args.cpu_seconds)}
         for v in variants[1:]:                         # the other variant: a shorter sample, mainly for its parity check
             cpu[v] = scipy_baseline(g, spec["hop"], v, args.cpu_seconds / 3)
-        cpu_pool = scipy_pool_baseline(g, spec["hop"], primary_v, min(10.0, args.cpu_seconds), cpu[primary_v]["rate"])
+        if world == 1:
+            cpu_pool = scipy_pool_baseline(g, spec["hop"], primary_v, min(10.0, args.cpu_seconds), cpu[primary_v]["rate"])
+
+    dist = None
+    if world > 1:
+        # control plane only (unique-id broadcast, barriers, max over ranks); the data-plane
+        # exchange is the library's own ncclAllGather over RCCL
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rk = Ranks(dist, rank, world)
 
     # HSD_COMM_DRYRUN=1 rehearses the multi-rank flow on a box with fewer GPUs than ranks: every rank on GPU 0,
     # no RCCL communicator, the signature exchange through the host (gloo) -- never a measurement
@@ -928,14 +1057,15 @@ def main():
             sec = variant_summary(r["variants"][variants[1]])
             if cpu and variants[1] in cpu and "error" not in sec:
                 sec["cpu_baseline"] = cpu_entry(cpu[variants[1]], variants[1], spec["hop"], "the same matrix")
-        line = {
-            "metric": "node-pairs/sec on NxN structural-distance matrix",
+        detail = {
+            "metric": METRIC,
             "value": prim["pairs_per_s"], "unit": "node-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": prim["dtype"],
             "data": "synthetic" if not dryrun else "synthetic (HSD_COMM_DRYRUN rehearsal: all ranks on one GPU, not a measurement)",
             "config": {"workload": f"{spec['name']}, degree-histogram signatures, variant {primary_v} ({variant_call(primary_v) if wass else 'KL on alpha-smoothed ring histograms'}; "
                                    f"layers {prim['lo']}..{prim['hi']}), full symmetric fp64 matrix resident in HBM",
+                       "workload_short": f"{spec['name']}; degree-histogram signatures, variant {primary_v}, layers {prim['lo']}..{prim['hi']}; full symmetric fp64 matrix in HBM",
                        "nodes": n, "edges": g.n_edge, "hop": spec["hop"], "bins": r["n_bins"],
                        "parallelism": f"row-block x{world}" + (" (contiguous blocks of equal planned cost, hsd_pair_shard)" if world > 1 else ""),
                        "rows_of_rank0": list(prim["rows"])},
@@ -958,7 +1088,7 @@ def main():
             "configs": configs,
             "device": info["arch"], "cus": info["compute_units"],
         }
-        print(json.dumps(line), flush=True)
+        emit(detail, args.detail)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

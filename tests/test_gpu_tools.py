@@ -74,11 +74,19 @@ def test_bench_line_contract(tmp_path):
     import sys
     from conftest import REPO
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--graph", "ba", "--nodes", "20000",
-                        "--cpu-seconds", "1.5", "--configs", "none"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+                        "--cpu-seconds", "1.5", "--configs", "none", "--detail", "bench_detail_contract_test.json"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines[:3]
-    d = json.loads(lines[0])
+    # stdout is the contract line and nothing else: compact (the driver reads a tail of stdout -- round 4's 20 KB line was lost), strict JSON
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), lines[:3]
+    assert len(lines[0].encode()) < 4096, len(lines[0])
+
+    def no_constants(name):
+        raise ValueError(f"{name} is not JSON")
+    d = json.loads(lines[0], parse_constant=no_constants)
+    # everything else measured went to the detail record (next to bench.py, under gpurun_out/, and on stderr)
+    detail = json.load(open(os.path.join(REPO, d["detail"])), parse_constant=no_constants)
+    assert detail["value"] == d["value"] and detail["roofline"]["kernel_ms"] == d["roofline"]["kernel_ms"] and "phases_s" in detail
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(d[k], t), (k, d[k])
