@@ -100,7 +100,7 @@ struct hsd_ctx {
     int elem_bytes = 0;
     void *d_X = nullptr;               // fp64 or u32 [dcols][npad]
     void *d_Y = nullptr;               // KL: log P, same shape
-    double *d_H = nullptr;             // KL: sum_c P log P per node [npad]
+    double *d_H = nullptr;             // [2 npad]: KL: sum_c P log P per node, then the ring-0 values; W1: the ring-0 values
     HsdSegDesc seg_tab[HSD_MAX_LAYERS] = {};   // zero-pad: per layer segment, bin-form / rank-form columns
     HsdSegDesc *d_seg_tab = nullptr;
     uint32_t *d_rmax = nullptr;        // zero-pad rank form: largest ring per layer and 64-node granule [n_seg][ngran]
@@ -122,7 +122,9 @@ struct hsd_ctx {
     double *d_inv = nullptr;           // zero-pad: 1/ring size per layer [n_seg][npad]
     int n_seg = 0;                     // zero-pad: number of layer segments
     int seg_valid16 = 0;               // PAIR_SAD_U16: packed data columns per segment
-    bool has_point = false;            // W1 with layer 0: ring-0 values live in d_H and add |p_i - p_j|
+    bool has_point = false;            // W1 with layer 0: ring-0 values live in d_H and add |p_i - p_j|; KL with layer 0 in closed
+                                       // form: they follow the entropy term (d_H + npad) and add kl_point_c where they differ
+    double kl_point_c = 0.0;
     int seg_begin[HSD_MAX_LAYERS + 1] = {0};   // column range of each segment (chunk aligned)
     int *d_flag = nullptr;             // device error flag (empty ring, ...)
 

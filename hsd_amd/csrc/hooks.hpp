@@ -37,6 +37,7 @@ enum HsdHook {
     H_PLAN_THREADS_FAIL,
     H_U8,
     H_SHARD_BALANCE,
+    H_KL_POINT,
     H_DEBUG,
     H_SIDE_STREAMS,
     H_TOPK_DEBUG,

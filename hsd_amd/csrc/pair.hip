@@ -67,7 +67,8 @@ struct PairArgs {
     const void *Y;          // J-side operand (same as X for the L1 kernels)
     const double *H;        // DOT: per-node entropy term
     const double *inv;      // segmented: [n_seg][npad]
-    const double *point;    // optional ring-0 value per node [npad] (adds |p_i - p_j|)
+    const double *point;    // optional ring-0 value per node [npad] (W1: adds |p_i - p_j|; DOT: adds point_c where p_i != p_j)
+    double point_c;         // DOT: KL of two different point masses on the smoothed support (closed form of layer 0, prepare_kl)
     double *out;
     int64_t ld, npad;
     int64_t rbase;          // out row 0 <-> node rbase
@@ -616,7 +617,10 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
         for (int r = 0; r < TR; ++r) {
             const double pi = gpoint[i0 + wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) acc[r][cc] += fabs(pi - pj[cc]);
+            for (int cc = 0; cc < TC; ++cc) {
+                if constexpr (KIND == K_DOT) acc[r][cc] += (pi != pj[cc]) ? a.point_c : 0.0;      // ring 0 of KL: two point masses
+                else acc[r][cc] += fabs(pi - pj[cc]);
+            }
         }
     }
 
@@ -938,7 +942,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         asm volatile("" ::: "memory");
         for (int v = 0; v < a.n_aux; ++v) {
             if ((v & (NW - 1)) != w) continue;
-            gcdouble *src = v < a.n_seg ? ginv + (int64_t)v * a.npad : (gpoint ? gpoint : gH);
+            // (DOT: the entropy term, then -- closed form of ring 0 -- the ring-0 values; layer kinds: 1/ring size per layer, then the ring-0 values)
+            gcdouble *src = v < a.n_seg ? ginv + (int64_t)v * a.npad : (KIND == K_DOT ? (v == a.n_seg ? gH : gpoint) : (gpoint ? gpoint : gH));
             const uint32_t dst = lds_off(aux + (buf * a.n_aux + v) * AUX_STRIDE);
             glds16_s(reinterpret_cast<uint64_t>(src), aoffI, dst);
             glds16_s(reinterpret_cast<uint64_t>(src), aoffJ, dst + 1024u);
@@ -1509,14 +1514,17 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         if (!SEG && gpoint) {
             double pj[TC];
             const int lv = lane(), wi = (w >> 1) * 64 + 2 * lane_y(lv), wj = (w & 1) * 64 + 2 * lane_x(lv);
-            const double *ax = aux + (cur * a.n_aux + a.n_seg) * AUX_STRIDE;
+            const double *ax = aux + (cur * a.n_aux + a.n_seg + (KIND == K_DOT ? 1 : 0)) * AUX_STRIDE;
 #pragma unroll
             for (int cc = 0; cc < TC; ++cc) pj[cc] = ax[128 + wj + 16 * (cc >> 1) + (cc & 1)];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 const double pi = ax[wi + 16 * (r >> 1) + (r & 1)];
 #pragma unroll
-                for (int cc = 0; cc < TC; ++cc) ACC(r, cc) += fabs(pi - pj[cc]);
+                for (int cc = 0; cc < TC; ++cc) {
+                    if constexpr (KIND == K_DOT) ACC(r, cc) += (pi != pj[cc]) ? a.point_c : 0.0;     // ring 0 of KL: two point masses
+                    else ACC(r, cc) += fabs(pi - pj[cc]);
+                }
             }
         }
         // ---- stores ----
@@ -2281,7 +2289,9 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     if (a.i_end <= a.i_begin || a.j_end <= a.j_begin) return HSD_OK;
     const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
-    const int n_aux = ctx->n_seg + ((wass ? a.point != nullptr : true) ? 1 : 0);
+    const bool dot = ctx->mode == PAIR_KL || ctx->mode == PAIR_SKL;
+    // (KL kinds: the entropy term, + the ring-0 values when layer 0 is taken in closed form)
+    const int n_aux = ctx->n_seg + (dot ? (a.point ? 2 : 1) : ((wass ? a.point != nullptr : true) ? 1 : 0));
     // LDS budget of the persistent kernel (2 workgroups per CU): two tiles x three vectors x 2 KiB; deeper hierarchies
     // (more than two compared histogram layers + ring 0) take the one-tile kernel for every tile
     const int nw = (allow_stream && n_aux <= 3) ? stream_waves(ctx, a) : 0;
@@ -3272,11 +3282,50 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     return HSD_OK;
 }
 
+// ring 0 = {i}: its histogram is the point mass at node_bin[i] -- unless the caller uploaded other counts (hsd_signature_set_counts); flag bit 2 then
+__global__ void kl_point_kernel(PrepArgs p, double *__restrict__ point) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const uint32_t *c = p.counts + (int64_t)i * p.L * p.B;
+    uint32_t tot = 0;
+    for (int b = 0; b < p.B; ++b) tot += c[b];
+    const int nb = p.node_bin[i];
+    if (tot != 1u || c[nb] != 1u) atomicOr(p.flag + 1, 4);
+    point[i] = (double)nb;
+}
+
+// KL of layer 0 in closed form.  Ring 0 of node i is the point mass at its own bin b_i, so on the smoothed support
+// P_i(b) = ([b == b_i] + alpha) / Z, Z = 1 + alpha B, and sum_b P_i log(P_i / P_j) has two values only:
+//   0 where b_i == b_j, and  ((1 + alpha) - alpha) (log((1 + alpha) / Z) - log(alpha / Z)) / Z = log((1 + alpha) / alpha) / Z  elsewhere
+// -- the same both ways (so the symmetric form adds the same constant), and sorted histograms (kl_sorted) of two point masses are
+// equal: nothing to add.  The B dense columns of that layer (a sixth of config 3's arithmetic, a quarter at K = 3) become one compare
+// per pair in the tile epilogue, where W1 adds its own ring-0 term |v_i - v_j|.  HSD_KL_POINT=0: layer 0 stays in the dense loop.
 int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metric, double kl_alpha, int kl_sorted) {
     const int64_t n = p.n, npad = p.npad;
     const int B = p.B, L = p.L;
     const int sym = metric == HSD_METRIC_SYMMETRIC_KL;
     constexpr int CH = chunk_cols(K_DOT);
+    ctx->has_point = false;
+    ctx->kl_point_c = 0.0;
+    bool closed = p.layer_lo == 0 && nl >= 2 && kl_alpha > 0.0 && hsd_hook_int(H_KL_POINT, 1) != 0;
+    if (closed) {
+        // (d_H holds two vectors for the KL kinds: the entropy term [npad], then the ring-0 values [npad])
+        hipLaunchKernelGGL(kl_point_kernel, dim3(grid.x), block, 0, ctx->stream, p, ctx->d_H + npad);
+        int flag[4] = {0, 0, 0, 0};
+        HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag + 1, 0, sizeof(int), ctx->stream));
+        if (flag[1] & 4) closed = false;            // ring 0 is not the node itself somewhere (caller-assigned rings): the dense loop
+    }
+    if (closed) {
+        p.layer_lo = 1;
+        nl -= 1;
+        grid.y = (unsigned)nl;
+        if (!kl_sorted) {
+            ctx->has_point = true;
+            ctx->kl_point_c = (log((1.0 + kl_alpha) / kl_alpha)) / (1.0 + kl_alpha * (double)B);
+        }
+    }
     const int half = (int)round_up((int64_t)nl * B, CH);
     ctx->dcols = sym ? 2 * half : half;
     ctx->dcols_alg = (sym ? 2 : 1) * nl * B;
@@ -3317,8 +3366,8 @@ int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int lay
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nl), block(256);
     int rc;
     // d_H: per-node entropy term (KL) or the ring-0 point values (W1 with layer 0)
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)npad))) return rc;
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)npad * sizeof(double), ctx->stream));
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)2 * npad))) return rc;
+    HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)2 * npad * sizeof(double), ctx->stream));
     if (metric == HSD_METRIC_WASSERSTEIN) {
         const int nl_hist = nl - (layer_lo == 0 ? 1 : 0);
         rc = align == HSD_ALIGN_NONE ? prepare_w1_raw(ctx, p, grid, block, nl_hist) : prepare_w1_zeropad(ctx, p, grid, block, nl_hist);
@@ -3331,8 +3380,8 @@ int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int lay
     HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     HSD_HIP(ctx, hipGetLastError());
-    // ring-0 point values in use? (d_H doubles as the point array for W1)
-    ctx->has_point = metric == HSD_METRIC_WASSERSTEIN && layer_lo == 0;
+    // ring-0 point values in use? (W1: d_H is the point array; KL: prepare_kl decided, the point array follows the entropy term)
+    if (metric == HSD_METRIC_WASSERSTEIN) ctx->has_point = layer_lo == 0;
     if (metric == HSD_METRIC_WASSERSTEIN && align == HSD_ALIGN_NONE && (flag[0] & 1))
         return hsd_fail(ctx, HSD_ERR_EMPTY_RING, "Distribution can't be empty.");
     if (metric != HSD_METRIC_WASSERSTEIN && (flag[0] & 2))
@@ -3366,8 +3415,7 @@ extern "C" int hsd_pair_prepare(hsd_ctx *ctx, int metric, int align, int layer_l
 extern "C" int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element) try {
     HSD_CHECK_CTX(ctx);
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
-    if (n_columns) *n_columns = ctx->dcols_alg + ((wass && ctx->has_point) ? 1 : 0);
+    if (n_columns) *n_columns = ctx->dcols_alg + (ctx->has_point ? 1 : 0);
     if (bytes_per_element) *bytes_per_element = ctx->elem_bytes;
     return HSD_OK;
 } HSD_ABI_GUARD(ctx)
@@ -3471,7 +3519,8 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
     a.Y = wass ? ctx->d_X : ctx->d_Y;
     a.H = wass ? nullptr : ctx->d_H;
     a.inv = ctx->d_inv;
-    a.point = (wass && ctx->has_point) ? ctx->d_H : nullptr;
+    a.point = ctx->has_point ? (wass ? ctx->d_H : ctx->d_H + ctx->npad) : nullptr;
+    a.point_c = ctx->kl_point_c;
     a.npad = ctx->npad;
     a.dcols = ctx->dcols;
     a.n_seg = ctx->n_seg;
@@ -4113,7 +4162,8 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     a.Y = wass ? ctx->d_X : ctx->d_Y;
     a.H = wass ? nullptr : ctx->d_H;
     a.inv = ctx->d_inv;
-    a.point = (wass && ctx->has_point) ? ctx->d_H : nullptr;
+    a.point = ctx->has_point ? (wass ? ctx->d_H : ctx->d_H + ctx->npad) : nullptr;
+    a.point_c = ctx->kl_point_c;
     a.npad = ctx->npad;
     a.dcols = ctx->dcols;
     a.n_seg = ctx->n_seg;

@@ -136,6 +136,75 @@ def test_kl_golden(engine, name):
     assert np.allclose(Ds[iu], Gs[iu], rtol=RTOL, atol=ATOL)
 
 
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("n,p,K", [(1500, 0.006, 3), (700, 0.02, 2), (5000, 0.002, 3)])
+def test_kl_ring0_closed_form_equals_the_dense_layer(engine, n, p, K):
+    """Ring 0 of a node is the point mass at its own degree bin, so layer 0 of KL / symmetric KL (tools/metrics.py:74-88 on the smoothed
+    histograms) is a two-valued function of `same bin?` -- taken in the tile epilogue instead of B dense columns.  Same matrix as with the
+    layer in the dense loop (HSD_KL_POINT=0) up to the rounding of one added constant, B fewer operand columns, for the persistent and the
+    one-tile kernel, whole matrix and row block, every alpha; sorted histograms (calculate_distance's np.sort) of two point masses are equal."""
+    from hsd_amd.graph import erdos_renyi
+    g = erdos_renyi(n, p, 5)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(K)
+    B = int(engine.signature_dims()[1])
+    for metric in (1, 2):
+        for alpha, srt in ((0.5, False), (0.01, False), (2.0, False), (0.5, True)):
+            def matrix(stream):
+                def run():
+                    engine.pair_prepare(metric, 0, 0, K, alpha, srt)
+                    cols = engine.pair_operand_dims()[0]
+                    return engine.pair_rows_host(), engine.pair_rows_host(n // 3, n // 3 + 200), cols
+                return _with_env("HSD_STREAM", stream, run)
+            dense, dense_blk, cols_dense = _with_env("HSD_KL_POINT", "0", lambda: matrix("1"))
+            for stream in ("1", "0"):
+                D, blk, cols = matrix(stream)
+                assert cols_dense == (metric == 2 and 2 or 1) * (K + 1) * B
+                assert cols == (metric == 2 and 2 or 1) * K * B + (0 if srt else 1)
+                assert np.allclose(D, dense, rtol=1e-12, atol=1e-13), (metric, alpha, srt, stream, np.abs(D - dense).max())
+                assert np.allclose(blk, dense_blk, rtol=1e-12, atol=1e-13)
+                assert np.array_equal(blk, D[n // 3:n // 3 + 200]) or metric == 2
+    # ring 0 alone (layers 0..0) and alpha = 0 keep the dense loop (nothing else to compute / log 0)
+    engine.pair_prepare(1, 0, 0, 0, 0.5, False)
+    assert engine.pair_operand_dims()[0] == B
+    D0 = engine.pair_rows_host()
+    deg = g.degree
+    want = np.where(deg[:, None] != deg[None, :], np.log(1.5 / 0.5) / (1 + 0.5 * B), 0.0)
+    assert np.allclose(D0, want, rtol=1e-12, atol=1e-14)
+
+
+def test_kl_ring0_closed_form_needs_ring0_to_be_the_node(engine):
+    """Caller-assigned counts (hsd_signature_set_counts: the route of caller-assigned hierarchies, model/HSD.py:36 + tests/robust_test/main.py:179)
+    whose ring 0 is not the node itself: the closed form does not apply, the layer stays dense -- the same matrix as HSD_KL_POINT=0."""
+    from hsd_amd.graph import erdos_renyi
+    g = erdos_renyi(900, 0.01, 9)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(2)
+    B = int(engine.signature_dims()[1])
+    counts = engine.signature_counts().copy()
+    counts[17, 0] = counts[17, 1]                  # node 17's "ring 0" is its neighbourhood
+    engine.signature_set_counts(0, g.n_node, counts)
+    engine.pair_prepare(1, 0, 0, 2, 0.5, False)
+    assert engine.pair_operand_dims()[0] == 3 * B
+    D = engine.pair_rows_host()
+    ref = _with_env("HSD_KL_POINT", "0", lambda: (engine.pair_prepare(1, 0, 0, 2, 0.5, False), engine.pair_rows_host())[1])
+    assert np.array_equal(D, ref)
+    engine.signature_build_degree(2)               # back to the graph's own rings: closed form again
+    engine.pair_prepare(1, 0, 0, 2, 0.5, False)
+    assert engine.pair_operand_dims()[0] == 2 * B + 1
+
+
 @pytest.mark.parametrize("n,p,K,seed", [(2000, 0.004, 3, 1), (3001, 0.003, 2, 2), (777, 0.02, 3, 3)])
 def test_w1_vs_c_oracle_medium(engine, n, p, K, seed):
     """Seeded ER graphs (odd sizes, ragged tiles) against the C oracle on sampled rows."""

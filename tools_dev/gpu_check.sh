@@ -1,15 +1,10 @@
 #!/bin/bash
-# run on the GPU box: tests, bench, kernel-trace profile (summaries land in gpurun_out/)
+# run on the GPU box: tests, bench as the driver runs it (stdout = the contract line only), the multi-rank rehearsal's line
 set -o pipefail
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
 tail -2 gpurun_out/pytest_gpu.log
-timeout -k 10 300 python bench.py "$@" > gpurun_out/bench.log 2>&1 || { tail -30 gpurun_out/bench.log; exit 1; }
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench.log').read().strip().splitlines()[-1])
-print('A' if d['dtype']=='f64' else 'B', d['value'], d['ms_per_step'], d['roofline'])
-print('sec', d['secondary'])
-print(d['cpu_baseline'], d['parity'], d['phases_s'])
-PY
+timeout -k 10 400 python bench.py "$@" > gpurun_out/bench.stdout 2> gpurun_out/bench.stderr || { tail -30 gpurun_out/bench.stderr; exit 1; }
+wc -c gpurun_out/bench.stdout
+cat gpurun_out/bench.stdout
