@@ -30,6 +30,7 @@ METRIC_KL = 1
 METRIC_SYMMETRIC_KL = 2
 ALIGN_NONE = 0
 ALIGN_ZEROPAD = 1
+ABI_VERSION = 2          # HSD_ABI_VERSION of include/hsd.h this binding was written against
 
 
 class DeviceInfo(C.Structure):
@@ -103,11 +104,21 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C hsd_amd/csrc`). "
             "hsd_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    rebuild = "rebuild it: `make -C hsd_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`)"
+    try:
+        lib.hsd_abi_version.restype = _int
+        lib.hsd_abi_version.argtypes = []
+        version = lib.hsd_abi_version()
+    except AttributeError:
+        raise ImportError(f"{LIB_PATH} does not export hsd_abi_version: not a libhsd_amd.so; {rebuild}") from None
+    if version != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {version}, this package binds version {ABI_VERSION} (include/hsd.h): a stale library; {rebuild}")
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError(f"{LIB_PATH} does not export {name} although its ABI version matches: a stale or partial build; {rebuild}") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.hsd_abi_version() != 1:
-        raise ImportError("libhsd_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -20,7 +20,7 @@
 // arithmetic: every region with >= 11 (integer kinds) / 16 (fp64) tiles per resident workgroup -- and pair_kernel, one tile per workgroup: small regions
 // (64 x 64 tiles, ~5 workgroups per CU), strips at the end of a range, KL's diagonal tiles.  Both produce the same bits per
 // pair.  DESIGN.md section 5 holds the measurements behind each choice.
-#include "common.hpp"
+#include "pair_internal.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -33,112 +33,10 @@
 #include <thread>
 #include <type_traits>
 
-namespace {
+using namespace hsd_pair;
 
-#ifndef HSD_PIN
-#define HSD_PIN 1
-#endif
-#ifndef HSD_STORE_BITS
-#define HSD_STORE_BITS "nt"     // cache-policy bits of the persistent kernel's result stores (measured: see DESIGN.md section 5)
-#endif
-#ifndef HSD_ABLATE
-#define HSD_ABLATE 0            // measurement builds only (wrong results): bit 0: no accumulator exchange; bits 2 / 3: only the direct / mirrored half is stored
-#endif
-#ifndef HSD_STAMPS
-#define HSD_STAMPS 0                // 1: the persistent kernel carries its in-kernel cycle stamps (HSD_DEBUG bit 3) and the plain-store switch
-#endif                              //    (bit 2) -- a measurement build: a dozen scalar registers the product kernel needs for itself
-#ifndef HSD_F64_UNROLL
-#define HSD_F64_UNROLL 4            // columns per straight-line trip of the fp64 inner loops (2 = the plain two-column loop)
-#endif
-#if HSD_PIN
-#define HSD_PIN_ORDER __builtin_amdgcn_sched_barrier(0)
-#else
-#define HSD_PIN_ORDER ((void)0)
-#endif
-
-// operand columns per LDS stage: 16 fp64 or 32 uint32 columns (the same LDS bytes); segments of
-// the operand matrices are padded to this width by hsd_pair_prepare
-__host__ __device__ constexpr int chunk_cols(int kind) { return (kind == 1 || kind == 4) /* uint32 kinds */ ? 32 : 16; }
-constexpr int NT = 256;             // 4 waves; wave w owns quadrant (w>>1, w&1) of the tile
-
-struct SegDesc;
-struct PairArgs {
-    const void *X;          // I-side operand, bin-major [dcols][npad]
-    const void *Y;          // J-side operand (same as X for the L1 kernels)
-    const double *H;        // DOT: per-node entropy term
-    const double *inv;      // segmented: [n_seg][npad]
-    const double *point;    // optional ring-0 value per node [npad] (W1: adds |p_i - p_j|; DOT: adds point_c where p_i != p_j)
-    double point_c;         // DOT: KL of two different point masses on the smoothed support (closed form of layer 0, prepare_kl)
-    double *out;
-    int64_t ld, npad;
-    int64_t rbase;          // out row 0 <-> node rbase
-    int64_t i_begin, i_end, j_begin, j_end;
-    int tiles_i, tiles_j, ntiles;
-    const int2 *tiles;      // optional explicit tile order (super-tile major), ntiles entries
-    int n_aux;              // persistent kernel: per-node vectors (1/ring size per layer, ring-0 value, entropy) staged through
-                            // LDS with every tile (0: read from global memory where they are needed)
-    int sym;                // square region on the diagonal: only tiles on/above it are enumerated
-    int mirror;             // also write the transposed tile (the region's mirror image belongs to this call); 2: per tile, bit 30 of its row index
-    int swap;               // DOT below the diagonal: value(i,j) = H[j] - X_j . Y_i
-    int hmode;              // DOT: 0 -> H[i] - acc ; 1 -> (H[i] + H[j] - acc) / 2
-    int dcols, n_seg;
-    int dcols_valid;        // columns that carry data (non-segmented kinds)
-    const struct SegDesc *seg_tab;   // segmented kinds: per layer, where its bin-form / rank-form columns live
-    const uint32_t *rmax;   // [n_seg][ngran] largest ring of the layer within each 64-node granule (rank form)
-    int ngran;
-    int list_cap;           // entries of the per-tile chunk list in LDS
-    unsigned long long *work;   // += operand words x pairs evaluated (hsd_pair_work), or nullptr
-    int *tile_ctr;          // persistent kernel: [8] tiles drawn so far from each XCD's run (zeroed before the launch)
-    int ctr_slot;           // which of the context's counter sets this region uses (regions of a row block run side by side)
-    int phase, n_phases;    // host side: this launch covers the tile groups of phase `phase` of `n_phases` (0 / 0: all of them)
-    int phase_w;            // ... of the phases [phase, phase + phase_w) (0 counts as 1): a sweep's later launches cover several
-    int dbg;                // HSD_DEBUG ablation bits: 1 = no stores, 2 = no arithmetic
-    // fused k-nearest consumer (hsd_pair_topk): instead of storing the tile, every value below its
-    // row's threshold tau is appended to that row's candidate list
-    // persistent kernel: tile composition (eight 16-node granules per tile side) and the min form of rank segments
-    const int32_t *gl_i, *gl_j;     // granule lists of the region's row / column range, 8 entries per list tile
-    const uint32_t *tmax_i, *tmax_j;   // [n_seg][ntl]: most members above the segment's threshold among a list tile's nodes
-    int ntl_i, ntl_j;               // list tiles per side (row stride of tmax)
-    const uint32_t *suf;            // suffix sums of the rank columns [rows][npad] (HsdSegDesc::suf_row0)
-    const uint16_t *tau16;          // k-nearest sweep: this launch's thresholds as bfloat16 rounded UP, indexed like tau (persistent kernel)
-    unsigned long long *stamps;     // HSD_DEBUG bit 3: per-workgroup lifetimes (measurement), else nullptr
-    const double *tau;      // [n] per-node threshold, or nullptr for the normal matrix output
-    int *cand_cnt;          // [n] candidates appended so far (may exceed cand_cap: overflow)
-    int *cand_idx;          // [n][cand_cap]
-    double *cand_val;       // [n][cand_cap]
-    int cand_cap;
-    // pruned k-nearest sweep (raw fp64 W1, hsd_pair_topk): the operands are a node-PERMUTED copy (similar nodes adjacent), the kernel
-    // appends ORIGINAL node ids (orig_of[position]; < 0: a padding position, never a candidate); host side: an explicit tile list
-    // instead of tile_order's, and per-tile feature intervals that let launch_region drop tile pairs no row's threshold can reach
-    const int32_t *orig_of;
-    const int2 *explicit_tiles;     // host side only
-    int n_explicit;
-    const double *prune_lo, *prune_hi;   // host side only: [prune_nf][prune_nt]
-    const double *prune_scale;      // host side only: [prune_nf][prune_nt] smallest factor of the feature's gap within a tile (nullptr: 1)
-    int prune_nf, prune_nt, prune_drop_band;
-    const int32_t *gl_ov;           // host side only: the region's granule list and its per-tile maxima given by the caller (permuted operands)
-    const uint32_t *tmax_ov;
-    int ntl_ov;
-};
-
-enum { K_L1 = 0, K_SAD = 1, K_ZP = 2, K_DOT = 3, K_SAD16 = 4 };
-constexpr int TILE_MIRROR_FLAG = 1 << 30, TILE_INDEX_MASK = TILE_MIRROR_FLAG - 1;   // explicit tile lists of row-block launches (PairArgs::mirror == 2)
-
-template <int KIND> struct Elem { using type = double; };
-template <> struct Elem<K_SAD> { using type = uint32_t; };
-template <> struct Elem<K_SAD16> { using type = uint32_t; };      // two uint16 columns per word
-template <typename T> struct Vec2;
-template <> struct Vec2<double> { using type = double2; };
-template <> struct Vec2<uint32_t> { using type = uint2; };
-
-// pointers that arrive inside the argument struct lose their address space; typed global
-// pointers make the compiler emit global_store / global_load instead of flat_* (flat accesses
-// also tick lgkmcnt and would serialise against the LDS operand reads)
-typedef __attribute__((address_space(1))) double gdouble;
-typedef double v2f64 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) v2f64 gdouble2;
-typedef __attribute__((address_space(1))) const double gcdouble;
-typedef __attribute__((address_space(1))) const uint32_t gcu32;
+// (named, not anonymous: tile_edge / stream_waves / launch_region are what pair_internal.hpp declares for the other translation units)
+namespace hsd_pair {
 
 __device__ inline int64_t uniform64(int64_t v) {
     // a wave-uniform value that the compiler may have left in vector registers: back to scalar registers
@@ -278,20 +176,6 @@ __device__ inline void store2_full(gdouble *p, double v0, double v1, bool nt) {
         p[1] = v1;
     }
 }
-
-// One layer ("segment") of a zero-pad distance has exact representations of the same integer
-//   S(i, j) = |n_i - n_j| s_0 + sum_b |T_i(b) - T_j(b)| (s_{b+1} - s_b)  =  sum_r |u_i(r) - u_j(r)|
-// (area between the two tail-count step functions T(x) = #members > x  =  L1 distance of the descending sorted samples,
-// zero padded), and the area may be cut at any value theta and each part taken in either form:
-//   bin form   one column per support bin (tail count x bin width), two uint16 columns per word
-//   rank form  one column per rank r: (r-th largest member value - theta)+, zeros beyond the members above theta
-//              -> ceil(R / 2) words, R = most members above theta among the nodes of the two tiles
-// A layer is stored as its bin columns (all of them, contiguous) and, in a second range, a copy of the bin columns below
-// theta followed by the rank columns above theta; a tile pair reads whichever range is shorter -- one contiguous run of
-// columns either way.  theta = 0 is the pure rank form (ring 1 of a scale-free graph:
-// ~10 members against 241 degree bins); ring 2 (hundreds of members, a few dozen of them hubs) keeps the dense low bins
-// and takes its sparse tail by rank.  Same integer either way, so the result is bit-identical.
-struct SegDesc : HsdSegDesc {};    // columns in words
 
 // The lanes append their segments' chunks {first column, valid | ends_segment << 8 | segment << 16} to the tile's list, the
 // LAST segment first (outer rings are the long ones: the persistent kernel lets the previous tile's result stores leave
@@ -744,8 +628,6 @@ __global__ __launch_bounds__(NT, TR == 8 ? 2 : 4) void pair_kernel(const PairArg
 // (HsdSegDesc::suf_row0: one uint32 per node and word index) to the integer accumulator before the layer's fold.  The same
 // integer as the bin form and the max form (tests/test_gpu_forms.py compares them bit for bit).
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int stream_chunk_cols(int kind) { return chunk_cols(kind); }
-
 // wait until at most `young` of this wave's vector-memory operations are outstanding (they retire in order, so that
 // means everything older than the `young` newest has landed); a smaller count than the true one only waits longer
 __device__ inline void wait_vm_young(int young) {
@@ -755,43 +637,6 @@ __device__ inline void wait_vm_young(int young) {
     else if (young >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (young >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// Lane l < n_seg holds segment l.  RI / RJ: most members above the segment's threshold among the nodes of the tile's two
-// sides.  Chooses bin form or (min form) rank form, appends the segment's chunks to the tile's list like plan_segment and
-// leaves in smeta[l] the suffix row to add and the side it belongs to (bit 30: the J side), or -1.
-// The form a tile pair reads a layer segment in (shared by the kernel's planner and by the host's cost estimate of a row partition):
-// first column, words, suffix row | side << 30 (or -1), leading uint16 words.
-struct SegChoice { int col0, words, sm, k16; };
-template <bool PACK>
-__host__ __device__ inline SegChoice choose_segment_form(const HsdSegDesc &sd, bool active, uint32_t RI, uint32_t RJ) {
-    SegChoice c{sd.bin_col0, active ? sd.bin_words : 0, -1, 1 << 20};
-    // (bit 31 of a side's maximum: one of its nodes holds a value >= 256 where the uint8 range has bytes)
-    const bool wide = ((RI | RJ) >> 31) != 0;
-    RI &= 0x7fffffffu; RJ &= 0x7fffffffu;
-    if (active && sd.rank_col0 >= 0 && sd.suf_row0 >= 0) {
-        const uint32_t Rm = RI < RJ ? RI : RJ;
-        int wr = PACK ? (int)((Rm + 1) >> 1) : (int)Rm;
-        if (sd.rank_low + wr == 0 && sd.rank_cap >= 1) wr = 1;      // a layer always closes with a fold (the longer side's suffix is added there)
-        if (wr <= sd.rank_cap) {
-            c.col0 = sd.rank_col0;
-            c.words = sd.rank_low + wr;
-            c.sm = (sd.suf_row0 + wr) | (RI >= RJ ? 0 : (1 << 30));
-            if (PACK && sd.r8_col0 >= 0 && !wide) {
-                // uint8 range: the rank words beyond the first r8_r16 two-into-one.  The columns end with the uint16 range's
-                // (zeros beyond its cap), so the suffix row is capped there too.
-                const int over = wr - sd.r8_r16, wr8 = over > 0 ? (over + 1) >> 1 : 0, w8 = sd.r8_fixed + wr8;
-                if (wr8 <= sd.r8_cap && w8 >= 1 && w8 < c.words) {
-                    const int srow = sd.r8_r16 + 2 * wr8;
-                    c.col0 = sd.r8_col0;
-                    c.words = w8;
-                    c.k16 = sd.r8_k16;
-                    c.sm = (sd.suf_row0 + (srow < sd.rank_cap ? srow : sd.rank_cap)) | (RI >= RJ ? 0 : (1 << 30));
-                }
-            }
-        }
-    }
-    return c;
 }
 
 template <int CH, bool PACK>
@@ -1654,245 +1499,6 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 }
 #undef ACC
 
-// ------------------------------------------------------------------------------------------
-// operand preparation (K2 finalise): counts -> bin-major operand matrices
-// ------------------------------------------------------------------------------------------
-struct PrepArgs {
-    const uint32_t *counts;     // [rows][L][B]
-    const double *support;      // [B]
-    const int32_t *node_bin;    // [n]
-    int64_t n, npad;
-    int L, B;                   // layers in the counts tensor, bins
-    int layer_lo, layer_hi;
-    int *flag;                  // flag[0] |= 1 : empty ring met
-};
-
-// W1 raw samples: column block of layer k>=1 holds G[b] = (cc[b]/n) * (s[b+1]-s[b]), b < B-1.
-// One thread per (node, layer).
-__global__ void prep_l1_kernel(PrepArgs p, double *__restrict__ X, int col_begin_first, int cols_per_layer,
-                               double *__restrict__ point) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = p.layer_lo + blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    if (k == 0) {               // ring 0 = {i}: W1 of two point masses = |v_i - v_j|
-        point[i] = p.support[p.node_bin[i]];
-        return;
-    }
-    uint32_t tot = 0;
-    for (int b = 0; b < p.B; ++b) tot += c[b];
-    if (tot == 0) atomicOr(p.flag, 1);
-    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
-    const int64_t cb = col_begin_first + (int64_t)(k - first) * cols_per_layer;
-    const double nn = (double)tot;
-    uint32_t cc = 0;
-    for (int b = 0; b + 1 < p.B; ++b) {
-        cc += c[b];
-        const double cdf = tot ? (double)cc / nn : 0.0;
-        X[(cb + b) * p.npad + i] = cdf * (p.support[b + 1] - p.support[b]);
-    }
-}
-
-// zero-pad alignment (tools/metrics.py:26-28): both samples padded with zeros to max(n_i, n_j),
-// so with tail counts T[b] = #members with value > s[b]:
-//   W1 = 1/max(n_i,n_j) * ( |n_i - n_j| * s[0] + sum_b |T_i[b] - T_j[b]| * (s[b+1]-s[b]) )
-// columns of layer k>=1: [ n*s[0], T[0]*d[0], ..., T[B-2]*d[B-2] ]  (B columns), inv = 1/n (2 if empty)
-template <typename T>
-__global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict__ inv, double *__restrict__ point,
-                               const int *__restrict__ seg_begin, uint32_t *__restrict__ ntot /* [n_seg][npad] ring sizes */) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = p.layer_lo + blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    if (k == 0) {
-        point[i] = p.support[p.node_bin[i]];
-        return;
-    }
-    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
-    const int s = k - first;
-    uint32_t tot = 0;
-    for (int b = 0; b < p.B; ++b) tot += c[b];
-    inv[(int64_t)s * p.npad + i] = tot ? 1.0 / (double)tot : 2.0;
-    ntot[(int64_t)s * p.npad + i] = tot;
-    const int64_t cb = seg_begin[s];
-    X[cb * p.npad + i] = (T)((double)tot * p.support[0]);
-    uint32_t tail = tot;
-    for (int b = 0; b + 1 < p.B; ++b) {
-        tail -= c[b];
-        X[(cb + 1 + b) * p.npad + i] = (T)((double)tail * (p.support[b + 1] - p.support[b]));
-    }
-}
-
-// Rank columns of a zero-pad layer above its threshold (SegDesc): word w of node i holds the (2w)-th and (2w+1)-th largest
-// of (member value - theta) over the members with bin index >= first_bin (PACK: two uint16 per word; else one uint32 per
-// word), zeros beyond them.  The histogram is walked from the top bin down; only the first `cap` words are kept (tile pairs
-// that would need more take the bin columns).
-template <bool PACK>
-__global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_col0, const int *__restrict__ seg_rank_cap,
-                                 const int *__restrict__ seg_first_bin, const int *__restrict__ seg_suf_row0, uint32_t *__restrict__ X,
-                                 uint32_t *__restrict__ SUF) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
-    const int sgi = blockIdx.y;
-    const int k = first + sgi;
-    if (i >= p.n || seg_rank_col0[sgi] < 0) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    const int cap = seg_rank_cap[sgi], fb = seg_first_bin[sgi];
-    const uint32_t theta = fb > 0 ? (uint32_t)p.support[fb - 1] : 0u;
-    uint32_t *col = X + (int64_t)seg_rank_col0[sgi] * p.npad + i;
-    // suffix sums (min form of the persistent kernel): suf[w] = sum of ALL the node's rank values from word w on, i.e. the
-    // whole sum above theta minus what the first w words hold -- also where the rank columns themselves are cut off at the cap
-    uint32_t *suf = SUF + (int64_t)seg_suf_row0[sgi] * p.npad + i;
-    uint32_t total = 0;
-    for (int b = p.B - 1; b >= fb; --b) total += c[b] * ((uint32_t)p.support[b] - theta);
-    const int want = PACK ? 2 * cap : cap;           // values to emit
-    int r = 0;
-    uint32_t lo = 0, prefix = 0;
-    suf[0] = total;
-    for (int b = p.B - 1; b >= fb && r < want; --b) {
-        const uint32_t v = (uint32_t)p.support[b] - theta;
-        for (uint32_t m = c[b]; m > 0 && r < want; --m, ++r) {
-            prefix += v;
-            if (PACK) {
-                if (r & 1) { col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16); suf[(int64_t)((r >> 1) + 1) * p.npad] = total - prefix; }
-                else lo = v;
-            } else {
-                col[(int64_t)r * p.npad] = v;
-                suf[(int64_t)(r + 1) * p.npad] = total - prefix;
-            }
-        }
-    }
-    if (PACK && (r & 1)) {                            // odd count: upper half stays 0
-        col[(int64_t)(r >> 1) * p.npad] = lo;
-        suf[(int64_t)((r >> 1) + 1) * p.npad] = total - prefix;
-    }
-    // (rows beyond the node's own words stay 0: the matrix was cleared)
-}
-
-// uint8 range of a packed layer (HsdSegDesc::r8_*): what node i needs to stay uint16 in the layer's rank-form range
-//   need[(2 s) * npad + i]     = leading low-bin words up to and including the last one that holds a value >= 256
-//   need[(2 s + 1) * npad + i] = leading rank words that hold a value >= 256 (the ranks are descending)
-__global__ void u8_need_kernel(const uint32_t *__restrict__ X, int64_t npad, int64_t n, const HsdSegDesc d, uint32_t *__restrict__ need) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = 0;
-    if (i >= n || d.rank_col0 < 0) return;
-    const auto wide = [](uint32_t v) { return (v & 0xffffu) >= 256u || (v >> 16) >= 256u; };
-    uint32_t b8 = 0, r8 = 0;
-    for (int w = 0; w < d.rank_low; ++w)
-        if (wide(X[(int64_t)(d.rank_col0 + w) * npad + i])) b8 = (uint32_t)w + 1u;
-    for (int w = 0; w < d.rank_cap; ++w) {
-        if (!wide(X[(int64_t)(d.rank_col0 + d.rank_low + w) * npad + i])) break;
-        r8 = (uint32_t)w + 1u;
-    }
-    need[(int64_t)(2 * s) * npad + i] = b8;
-    need[(int64_t)(2 * s + 1) * npad + i] = r8;
-}
-
-// dst word w = the four uint16 values of source words 2 w, 2 w + 1 as saturated bytes (source words from n_src on count as
-// zero).  Saturated bytes are never compared: a tile with such a node does not read the uint8 range.
-__global__ void pack_u8_kernel(uint32_t *__restrict__ X, int64_t npad, int src_col, int n_src, int dst_col, int n_dst) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int w = blockIdx.y;
-    if (i >= npad || w >= n_dst) return;
-    const uint32_t a = 2 * w < n_src ? X[(int64_t)(src_col + 2 * w) * npad + i] : 0u;
-    const uint32_t b = 2 * w + 1 < n_src ? X[(int64_t)(src_col + 2 * w + 1) * npad + i] : 0u;
-    const auto sat = [](uint32_t v) { return v > 255u ? 255u : v; };
-    X[(int64_t)(dst_col + w) * npad + i] = sat(a & 0xffffu) | (sat(a >> 16) << 8) | (sat(b & 0xffffu) << 16) | (sat(b >> 16) << 24);
-}
-
-// above[(s * n_cand + q) * npad + i] = members of ring layer s of node i with bin index >= cand_bin[q]
-__global__ void count_above_kernel(PrepArgs p, const int *__restrict__ cand_bin, int n_cand, uint32_t *__restrict__ above) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
-    const int sgi = blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + first + sgi) * p.B;
-    uint32_t run = 0;
-    int q = n_cand - 1;
-    for (int b = p.B - 1; b >= 0; --b) {
-        while (q >= 0 && cand_bin[q] > b) { above[((int64_t)sgi * n_cand + q) * p.npad + i] = run; --q; }
-        run += c[b];
-    }
-    for (; q >= 0; --q) above[((int64_t)sgi * n_cand + q) * p.npad + i] = run;
-}
-
-// rmax[s][g] = largest ring size of layer segment s within the 64-node granule g
-__global__ void granule_max_kernel(const uint32_t *__restrict__ ntot, int64_t npad, int ngran, uint32_t *__restrict__ rmax) {
-    const int g = blockIdx.x, sgi = blockIdx.y;
-    uint32_t v = ntot[(int64_t)sgi * npad + (int64_t)g * 64 + threadIdx.x];
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_down((int)v, o, 64));
-    if (threadIdx.x == 0) rmax[(int64_t)sgi * ngran + g] = v;
-}
-
-// g16[k][g] = largest of vec[k][16 g .. 16 g + 15] (k: layer x candidate threshold)
-__global__ void granule16_max_kernel(const uint32_t *__restrict__ vec, int64_t npad, int ngran16, uint32_t *__restrict__ g16) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (g >= ngran16) return;
-    const uint32_t *v = vec + (int64_t)k * npad + (int64_t)g * 16;
-    uint32_t m = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) m = max(m, v[e]);
-    g16[(int64_t)k * ngran16 + g] = m;
-}
-
-// KL: P = (c + alpha) / (n + alpha B), LP = log P, H = sum P LP.  symmetric: X = [P ; LP], Y = [LP ; P].
-__global__ void prep_kl_kernel(PrepArgs p, double alpha, int symmetric, int half_cols /* padded cols of one [P] block */,
-                               double *__restrict__ X, double *__restrict__ Y, double *__restrict__ Hpart /* [nl][npad] */) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int kk = blockIdx.y;
-    const int k = p.layer_lo + kk;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    uint32_t tot = 0;
-    for (int b = 0; b < p.B; ++b) tot += c[b];
-    if (tot == 0 && alpha == 0.0) atomicOr(p.flag, 2);
-    const double den = (double)tot + alpha * (double)p.B;
-    double h = 0.0;
-    for (int b = 0; b < p.B; ++b) {
-        const double P = ((double)c[b] + alpha) / den;
-        const double LP = log(P);
-        h += P * LP;
-        const int64_t col = (int64_t)kk * p.B + b;
-        X[col * p.npad + i] = P;
-        Y[col * p.npad + i] = LP;
-        if (symmetric) {
-            X[(half_cols + col) * p.npad + i] = LP;
-            Y[(half_cols + col) * p.npad + i] = P;
-        }
-    }
-    Hpart[(int64_t)kk * p.npad + i] = h;
-}
-
-__global__ void sum_layers_kernel(const double *__restrict__ Hpart, int nl, int64_t npad, int64_t n, double *__restrict__ H) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int k = 0; k < nl; ++k) s += Hpart[(int64_t)k * npad + i];
-    H[i] = s;
-}
-
-// ascending sort of each (node, layer) histogram -- tools/metrics.py:29-30 applied to the
-// probability vectors (a monotone map of the counts, so sorting counts is equivalent)
-__global__ void sort_counts_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int B, int Bp2) {
-    extern __shared__ uint32_t sh[];
-    const int64_t row = blockIdx.x;
-    for (int t = threadIdx.x; t < Bp2; t += blockDim.x) sh[t] = t < B ? in[row * B + t] : 0xFFFFFFFFu;
-    __syncthreads();
-    for (int k = 2; k <= Bp2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < Bp2; t += blockDim.x) {
-                const int x = t ^ j;
-                if (x > t) {
-                    const uint32_t a = sh[t], b = sh[x];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) { sh[t] = b; sh[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int t = threadIdx.x; t < B; t += blockDim.x) out[row * B + t] = sh[t];
-}
-
 template <int KIND, bool FAST, int TR>
 hipError_t launch_pair(hsd_ctx *ctx, const PairArgs &a, int grid, hipStream_t stream) {
     auto kern = pair_kernel<KIND, FAST, TR>;
@@ -2003,14 +1609,27 @@ const int2 *tile_order(hsd_ctx *ctx, int tiles_i, int tiles_j, int sym, int cls,
     return reinterpret_cast<const int2 *>(d);
 }
 
+// LDS of one persistent workgroup: two stages of two 128-node operand blocks (chunk_bytes = bytes of one node's chunk: 128 either
+// kind), chunk lists + lengths of two tiles, the three-slot tile-plan ring, suffix rows, the segment descriptions, the per-node vectors
+// and suffix sums of two tiles, the k-nearest sweep's thresholds.
+constexpr size_t stream_lds_bytes(size_t chunk_bytes, int list_cap, int n_aux, int n_seg, bool topk) {
+    return (size_t)2 * 2 * chunk_bytes * 128 + (size_t)2 * list_cap * sizeof(int2) + 16 + 3 * 24 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
+           (size_t)2 * n_aux * 256 * sizeof(double) + (size_t)2 * n_seg * 128 * sizeof(uint32_t) + (topk ? 512 : 0);
+}
+// BUILD-TIME GUARD of the occupancy the design depends on: two workgroups per CU need 2 x LDS <= 160 KiB.  The headline shape -- two zero-pad
+// layers + ring 0, i.e. three per-node vectors and two suffix vectors -- must keep it for the matrix kernel AND the k-nearest sweep with
+// chunk lists of up to 2 x (ceil(512 words / 32) + 2) + 1 entries (config 4's graph has 303 degree bins = 152 words per layer; round 3 lost
+// the second workgroup to 96 bytes of segment description at exactly this point: 87 -> 105-113 ms with every test green).  The fp64
+// kinds (raw W1 with three layers + ring 0: four vectors would not fit and take the one-tile kernel; KL with its two vectors) likewise.
+static_assert(2 * stream_lds_bytes(128, 2 * (16 + 2) + 1, 3, 2, true) <= 160 * 1024, "k-nearest sweep of the headline shape: ONE workgroup per CU");
+static_assert(2 * stream_lds_bytes(128, 2 * (16 + 2) + 1, 3, 2, false) <= 160 * 1024, "matrix kernel of the headline shape: ONE workgroup per CU");
+static_assert(2 * stream_lds_bytes(128, 1, 3, 0, true) <= 160 * 1024, "fp64 kinds with three per-node vectors: ONE workgroup per CU");
+
 template <int KIND, int NW, bool TOPK = false>
 hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
     auto kern = pair_stream_kernel<KIND, NW, TOPK>;
     constexpr int CH = stream_chunk_cols(KIND);
-    constexpr int BT = 128;
-    // stages, chunk lists + lengths, granule ids + suffix rows of two tiles, per-node vectors, suffix sums
-    const size_t lds = (size_t)2 * 2 * CH * BT * sizeof(typename Elem<KIND>::type) + (size_t)2 * a.list_cap * sizeof(int2) + 16 + 3 * 24 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
-                       (size_t)2 * a.n_aux * 256 * sizeof(double) + (size_t)2 * a.n_seg * 128 * sizeof(uint32_t) + (TOPK ? 512 : 0);
+    const size_t lds = stream_lds_bytes(CH * sizeof(typename Elem<KIND>::type), a.list_cap, a.n_aux, a.n_seg, TOPK);
     // (two workgroups per CU need 2 x lds <= 160 KiB: the integer kinds with three per-node vectors sit ~300 bytes below that -- at 96
     // bytes above it, after the segment descriptions had grown, the k-nearest sweep of BA N = 200k ran at half occupancy: 105 vs 66 ms)
     if (hsd_hook(H_PLAN_VERBOSE) && 2 * lds > (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor)
@@ -2104,21 +1723,6 @@ hipError_t launch_one_tile(hsd_ctx *ctx, const PairArgs &a, int BT, hipStream_t 
     }
 }
 
-// tmax[s * ntiles + t] = most members above layer s's threshold among the nodes of list tile t (its eight granules)
-__global__ void list_tile_max_kernel(const int32_t *__restrict__ gl, int ntiles, const uint32_t *__restrict__ rmax16, int ngran16, int n_seg,
-                                     uint32_t *__restrict__ tmax) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (int64_t)ntiles * n_seg) return;
-    const int s = (int)(k / ntiles), t = (int)(k % ntiles);
-    uint32_t m = 0, wide = 0;                        // bit 31: the granule holds a node too wide for the layer's uint8 range
-    for (int e = 0; e < 8; ++e) {
-        const uint32_t v = rmax16[(int64_t)s * ngran16 + gl[(int64_t)8 * t + e]];
-        m = max(m, v & 0x7fffffffu);
-        wide |= v & 0x80000000u;
-    }
-    tmax[k] = m | wide;
-}
-
 // tau16[i] = tau[i] rounded UP to bfloat16 (tau >= 0), i in [lo, hi)
 __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, int64_t hi, uint16_t *__restrict__ tau16) {
     const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2131,43 +1735,6 @@ __global__ void tau_bf16_up_kernel(const double *__restrict__ tau, int64_t lo, i
     tau16[i] = (uint16_t)b;
 }
 
-
-// ---- pruned k-nearest sweep (raw fp64 W1): features, permuted operands, tile filter ---------------------------------------------
-// Any partition of the columns gives a lower bound of an L1 distance: sum_c |x_c - y_c| >= sum_g |sum_{c in g} x_c - sum_{c in g} y_c|.
-// One group per layer (for the columns G = CDF x bin width that is |mean_i - mean_j| of the ring's values, the classic W1 bound) plus the
-// ring-0 point value: F[f][i], f < nl: sum of layer f's columns of node i; f == nl (if H): H[i].
-// (G > 1: every layer's columns in G consecutive groups -- a tighter bound, more features).  Two steps so that the sums have one fixed
-// order: blockIdx.y = feature x TK_SLICES + slice -> partial sums P[feature][slice][i]; then F[feature][i] = the slices added in order.
-constexpr int TK_SLICES = 16;
-__global__ void tk_feature_partial_kernel(const double *__restrict__ X, int64_t npad, int64_t n, int cpl, int G, double *__restrict__ P) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int f = blockIdx.y / TK_SLICES, sl = blockIdx.y % TK_SLICES, s = f / G, g = f % G;
-    const int c0 = s * cpl + (int)((int64_t)cpl * g / G), c1 = s * cpl + (int)((int64_t)cpl * (g + 1) / G);
-    const int a = c0 + (int)((int64_t)(c1 - c0) * sl / TK_SLICES), b = c0 + (int)((int64_t)(c1 - c0) * (sl + 1) / TK_SLICES);
-    double t = 0.0;
-    for (int c = a; c < b; ++c) t += X[(int64_t)c * npad + i];
-    P[((int64_t)f * TK_SLICES + sl) * n + i] = t;
-}
-__global__ void tk_feature_combine_kernel(const double *__restrict__ P, int64_t n, int nfh, const double *__restrict__ H, double *__restrict__ F) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int f = 0; f < nfh; ++f) {
-        double t = 0.0;
-        for (int sl = 0; sl < TK_SLICES; ++sl) t += P[((int64_t)f * TK_SLICES + sl) * n + i];
-        F[(int64_t)f * n + i] = t;
-    }
-    if (H) F[(int64_t)nfh * n + i] = H[i];
-}
-
-// Xp[c][p] = X[c][orig[p]] (0 at padding positions); blockIdx.y = column
-__global__ void tk_gather_kernel(const double *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, double *__restrict__ Xp) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npad) return;
-    const int32_t o = orig[p];
-    const int64_t c = blockIdx.y;
-    Xp[c * npad + p] = o >= 0 ? X[c * npad + o] : 0.0;
-}
 
 // largest threshold (bfloat16 patterns of non-negative values order like the values) among a tile's 128 positions
 __global__ void tk_tilemax_kernel(const uint16_t *__restrict__ tau16, int ntiles, uint16_t *__restrict__ tmax) {
@@ -2200,26 +1767,6 @@ __global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const do
     const double thr = (double)__uint_as_float(m << 16);
     // (the bound and the kernel's distances are sums of the same terms in different orders: a relative 1e-9 covers the rounding of both)
     if (lb * (1.0 - 1e-9) - 1e-9 <= thr) out[atomicAdd(count, 1)] = t;
-}
-
-// thresholds by node -> thresholds by position (0 at padding positions: nothing is at distance <= 0 from them but themselves)
-__global__ void tk_permute_tau_kernel(const int32_t *__restrict__ orig, int64_t npos, const double *__restrict__ tau_node, double *__restrict__ tau_pos) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npos) return;
-    const int32_t o = orig[p];
-    tau_pos[p] = o >= 0 ? tau_node[o] : 0.0;
-}
-
-// out[orig[p]] = in[p] for the rows p of real nodes (k entries per row)
-__global__ void tk_unpermute_kernel(const int32_t *__restrict__ orig, int64_t npos, int k, const int *__restrict__ idx_in, const double *__restrict__ val_in,
-                                    int *__restrict__ idx_out, double *__restrict__ val_out) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= npos * k) return;
-    const int64_t p = e / k, q = e % k;
-    const int32_t o = orig[p];
-    if (o < 0) return;
-    idx_out[(int64_t)o * k + q] = idx_in[e];
-    val_out[(int64_t)o * k + q] = val_in[e];
 }
 
 // The granule list of up to three node ranges [r[0], r[1]) + [r[2], r[3]) + [r[4], r[5]) taken one after the other (each begins on a
@@ -2285,7 +1832,7 @@ bool gran_list(hsd_ctx *ctx, int64_t begin, int64_t end, hipStream_t stream, hsd
     return gran_list_ranges(ctx, r, stream, out);
 }
 
-int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool allow_stream = true) {
+int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool allow_stream) {
     if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
     if (a.i_end <= a.i_begin || a.j_end <= a.j_begin) return HSD_OK;
     const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16;
@@ -2580,930 +2127,7 @@ int launch_square(hsd_ctx *ctx, const PairArgs &base, int64_t ra, int64_t re) {
     return launch_region(ctx, b, tile_edge(ctx), ctx->stream);
 }
 
-// per-column maximum of a uint32 bin-major matrix (one workgroup per column)
-__global__ __launch_bounds__(256) void colmax_u32_kernel(const uint32_t *__restrict__ X, int64_t npad, uint32_t *__restrict__ out) {
-    __shared__ uint32_t red[256];
-    const uint32_t *col = X + (int64_t)blockIdx.x * npad;
-    uint32_t m = 0;
-    for (int64_t i = threadIdx.x; i < npad; i += 256) m = max(m, col[i]);
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
-}
-
-// uint32 columns -> packed uint16 pairs.  Virtual column v of a segment is raw column vsrc[v] with
-// its bin width vdiv[v] replaced by the part vmul[v] of it (a column whose values T * width exceed
-// 65535 is split into several columns of smaller width: |T_i - T_j| * (d1 + d2) is the sum of both).
-__global__ void pack_u16_kernel(const uint32_t *__restrict__ X32, int64_t npad, int n_seg, int stride32, int V,
-                                const int *__restrict__ vsrc, const uint32_t *__restrict__ vdiv, const uint32_t *__restrict__ vmul,
-                                int stride16, uint32_t *__restrict__ X16) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = blockIdx.y;
-    if (i >= npad || s >= n_seg) return;
-    for (int c = 0; 2 * c < V; ++c) {
-        uint32_t w[2] = {0u, 0u};
-        for (int h = 0; h < 2; ++h) {
-            const int v = 2 * c + h;
-            if (v < V) w[h] = X32[((int64_t)s * stride32 + vsrc[v]) * npad + i] / vdiv[v] * vmul[v];
-        }
-        X16[((int64_t)s * stride16 + c) * npad + i] = w[0] | (w[1] << 16);
-    }
-}
-
-// The next (value, index) pair of a list in lexicographic order after (last_v, last_i), found by ONE WAVE: every lane scans
-// its share of the list, six exchange steps pick the minimum.  ci == nullptr: the position is the index (plain values).
-__device__ inline void wave_lex_next(const double *__restrict__ cv, const int *__restrict__ ci, int c, double last_v, int last_i, int lane,
-                                     double &ov, int &oi) {
-    double bv = INFINITY;
-    int bi = 0x7fffffff;
-    for (int t = lane; t < c; t += 64) {
-        const double v = cv[t];
-        const int i = ci ? ci[t] : t;
-        const bool after = v > last_v || (v == last_v && i > last_i);
-        if (after && (v < bv || (v == bv && i < bi))) { bv = v; bi = i; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double v = __shfl_xor(bv, o, 64);
-        const int i = __shfl_xor(bi, o, 64);
-        if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; }
-    }
-    ov = bv;
-    oi = bi;
-}
-
-// The same with the list held in registers (E entries per lane, loaded once) as order-preserving integer keys, each lane's
-// entries SORTED (odd-even transposition, once): a round is then one comparison of the lanes' heads over six exchange steps
-// plus a shift in the winning lane, instead of E lexicographic fp64 comparisons per lane.
-__device__ inline unsigned long long topk_key(double v) {            // monotone map of the doubles onto the unsigned integers
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ inline double topk_unkey(unsigned long long k) {
-    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
-}
-template <int E>
-struct WaveList {
-    unsigned long long key[E];
-    int i[E];
-    __device__ inline void load(const double *__restrict__ cv, const int *__restrict__ ci, int c, int lane) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int t = lane + 64 * e;
-            key[e] = t < c ? topk_key(cv[t]) : ~0ull;
-            i[e] = t < c ? (ci ? ci[t] : t) : 0x7fffffff;
-        }
-#pragma unroll
-        for (int p = 0; p < E; ++p)
-#pragma unroll
-            for (int e = p & 1; e + 1 < E; e += 2) {
-                const bool sw = key[e + 1] < key[e] || (key[e + 1] == key[e] && i[e + 1] < i[e]);
-                const unsigned long long k0 = sw ? key[e + 1] : key[e], k1 = sw ? key[e] : key[e + 1];
-                const int i0 = sw ? i[e + 1] : i[e], i1 = sw ? i[e] : i[e + 1];
-                key[e] = k0; key[e + 1] = k1; i[e] = i0; i[e + 1] = i1;
-            }
-    }
-    // the smallest entry still held by any lane; it is removed
-    __device__ inline void pop(double &ov, int &oi) {
-        unsigned long long bk = key[0];
-        int bi = i[0];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long xk = __shfl_xor(bk, o, 64);
-            const int xi = __shfl_xor(bi, o, 64);
-            if (xk < bk || (xk == bk && xi < bi)) { bk = xk; bi = xi; }
-        }
-        if (bk == key[0] && bi == i[0]) {
-#pragma unroll
-            for (int e = 0; e + 1 < E; ++e) { key[e] = key[e + 1]; i[e] = i[e + 1]; }
-            key[E - 1] = ~0ull;
-            i[E - 1] = 0x7fffffff;
-        }
-        ov = topk_unkey(bk);
-        oi = bi;
-    }
-};
-
-// tau[row] = the (k+1)-th smallest of the row's M sampled distances, slightly inflated.  One wave per row, k + 1 rounds of
-// "next smallest" (k is small against M; a bitonic sort of the sample in LDS took 2.2 ms for 100 000 rows of 1024).
-// The row's own node may be among the sampled columns (its distance is an exact 0 and comes first): the (k+1)-th smallest
-// keeps tau an upper bound of the k-th nearest OTHER node whether or not it is.  Inflated: the sweep may evaluate a pair
-// from the mirrored tile, whose fp64 sums are accumulated in another order (symmetric KL).
-// slack: absolute allowance on top (symmetric KL: H_i + H_j - dots cancels, so two evaluation orders of a pair of nearly
-// identical nodes differ by ~1e-15 ABSOLUTE, which no relative inflation of a tiny distance covers).
-__global__ __launch_bounds__(256) void topk_threshold_kernel(const double *__restrict__ S, int64_t ld, int M, int64_t row0, int64_t rows, int k,
-                                                            double slack, double *__restrict__ tau) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const double *sv = S + r * ld;
-    double last_v = -INFINITY;
-    int last_i = -1;
-    if (M <= 1024) {
-        WaveList<16> wl;
-        wl.load(sv, nullptr, M, lane);
-        for (int q = 0; q <= k; ++q) wl.pop(last_v, last_i);
-    } else {
-        for (int q = 0; q <= k; ++q) wave_lex_next(sv, nullptr, M, last_v, last_i, lane, last_v, last_i);
-    }
-    if (lane == 0) tau[row0 + r] = last_v + fabs(last_v) * 1e-12 + slack;
-}
-
-__global__ void fill_f64_kernel(double *__restrict__ p, int64_t n, double v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
-__global__ void fill_columns_kernel(double *__restrict__ S, int64_t ld, int64_t rows, int c_begin, int c_end, double v) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    for (int c = c_begin; c < c_end; ++c) S[r * ld + c] = v;
-}
-
-// The k smallest (value, index) pairs of each row's candidate list, ascending, ties by index: one wave per row, k rounds
-// of "next lexicographic minimum" (the lists are short).  flag[0] |= 1 on overflow or on a list shorter than k.
-__global__ __launch_bounds__(256) void topk_select_kernel(const int *__restrict__ cnt, const int *__restrict__ cidx,
-                                                         const double *__restrict__ cval, int cap, int64_t row0, int64_t rows, int k,
-                                                         int *__restrict__ out_idx, double *__restrict__ out_val, int *__restrict__ flag) {
-    const int lane = threadIdx.x & 63;
-    const int64_t lr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (lr >= rows) return;
-    const int64_t row = row0 + lr;
-    const int c = cnt[row];
-    if (c > cap || c < k) {
-        if (lane == 0) atomicOr(flag, 1);
-        return;
-    }
-    const int *ci = cidx + row * cap;
-    const double *cv = cval + row * cap;
-    double last_v = -INFINITY;
-    int last_i = -1;
-    if (c <= 512) {
-        WaveList<8> wl;
-        wl.load(cv, ci, c, lane);
-        for (int q = 0; q < k; ++q) {
-            wl.pop(last_v, last_i);
-            if (lane == 0) { out_idx[lr * (int64_t)k + q] = last_i; out_val[lr * (int64_t)k + q] = last_v; }
-        }
-        return;
-    }
-    for (int q = 0; q < k; ++q) {
-        wave_lex_next(cv, ci, c, last_v, last_i, lane, last_v, last_i);
-        if (lane == 0) { out_idx[lr * (int64_t)k + q] = last_i; out_val[lr * (int64_t)k + q] = last_v; }
-    }
-}
-
-// Between two phases of the sweep: a row whose list has grown beyond k entries keeps its k smallest (value, index) pairs
-// and takes the k-th value as its new threshold -- still an upper bound of its k-th nearest, and every later candidate
-// must beat it.  One wave per row.  Lists that overflowed are left alone (the select kernel reports them, the host retries).
-__global__ __launch_bounds__(256) void topk_compact_kernel(int *__restrict__ cnt, int *__restrict__ cidx, double *__restrict__ cval, int cap,
-                                                          int64_t rows, int k, double slack, double *__restrict__ tau) {
-    extern __shared__ double cmp_sh[];                 // per wave: k values, then k indices
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double *sel_v = cmp_sh + (size_t)w * k;
-    int *sel_i = reinterpret_cast<int *>(cmp_sh + (size_t)4 * k) + (size_t)w * k;
-    const int64_t row = (int64_t)blockIdx.x * 4 + w;
-    if (row >= rows) return;
-    const int c = cnt[row];
-    if (c > cap || c <= k) return;
-    int *ci = cidx + row * cap;
-    double *cv = cval + row * cap;
-    double last_v = -INFINITY;
-    int last_i = -1;
-    if (c <= 512) {
-        WaveList<8> wl;
-        wl.load(cv, ci, c, lane);
-        for (int q = 0; q < k; ++q) {
-            wl.pop(last_v, last_i);
-            if (lane == 0) { sel_v[q] = last_v; sel_i[q] = last_i; }
-        }
-    } else {
-        for (int q = 0; q < k; ++q) {
-            wave_lex_next(cv, ci, c, last_v, last_i, lane, last_v, last_i);
-            if (lane == 0) { sel_v[q] = last_v; sel_i[q] = last_i; }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < k; t += 64) { cv[t] = sel_v[t]; ci[t] = sel_i[t]; }
-    if (lane == 0) {
-        cnt[row] = k;
-        tau[row] = fmin(tau[row], last_v + fabs(last_v) * 1e-12 + slack);   // (inflated like the first threshold: mirrored evaluation order)
-    }
-}
-
-}  // namespace
-
-// ------------------------------------------------------------------------------------------
-namespace {
-
-// device temporary of hsd_pair_prepare: released on every exit path
-struct DevTmp {
-    void *p = nullptr;
-    ~DevTmp() { if (p) (void)hipFree(p); }
-    template <typename T> T *as() const { return static_cast<T *>(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    void *release() { void *q = p; p = nullptr; return q; }
-};
-
-#define HSD_TMP_ALLOC(ctx, tmp, bytes) HSD_HIP(ctx, (tmp).alloc(bytes))
-
-int prepare_w1_raw(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int nl_hist) {
-    // scipy on the raw samples: fp64 columns G = CDF x bin width, one block of B - 1 columns per layer >= 1
-    const int cpl = p.B - 1;
-    constexpr int CH = chunk_cols(K_L1);
-    ctx->dcols_alg = nl_hist * cpl;
-    ctx->dcols = (int)round_up(std::max(ctx->dcols_alg, 0), CH);
-    ctx->elem_bytes = 8;
-    const size_t cnt = (size_t)std::max(ctx->dcols, CH) * p.npad;
-    HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(prep_l1_kernel, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, 0, cpl, ctx->d_H);
-    ctx->mode = PAIR_L1_F64;
-    ctx->n_seg = 0;
-    ctx->l1_cols_per_layer = cpl;
-    return HSD_OK;
-}
-
-int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int nl_hist) {
-    const int64_t n = p.n, npad = p.npad;
-    const int B = p.B;
-    int rc;
-    // HSD_PLAN_VERBOSE: wall time of the stages (synchronising: measurement only)
-    const bool vt = hsd_hook(H_PLAN_VERBOSE) != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto mark = [&](const char *what) {
-        if (!vt) return;
-        (void)hipStreamSynchronize(ctx->stream);
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hsd plan] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
-        t_prev = t;
-    };
-    // the exact integer path needs integral supports and sums that fit uint32:
-    //   sum_c |U_i - U_j| <= (sum of member values of ring_k(i)) + (same for j) <= 2 * sum_v value(v)
-    bool use_u32 = ctx->support_integral;
-    if (use_u32) {
-        std::vector<int32_t> nb((size_t)n);
-        HSD_HIP(ctx, hipMemcpy(nb.data(), ctx->d_node_bin, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        long double tot = 0.0L;
-        for (int64_t i = 0; i < n; ++i) tot += ctx->support[(size_t)nb[(size_t)i]];
-        if (2.0L * tot >= 4294967295.0L) use_u32 = false;
-    }
-    const int CH = use_u32 ? chunk_cols(K_SAD) : chunk_cols(K_ZP);
-    const int stride = (int)round_up(B, CH);                 // unpacked bin columns per segment
-    const int nsg = std::max(nl_hist, 1);
-    ctx->n_seg = nl_hist;
-    ctx->elem_bytes = use_u32 ? 4 : 8;
-    for (int s = 0; s <= nl_hist; ++s) ctx->seg_begin[s] = s * stride;
-
-    // ---- bin form, unpacked: [ n*s0, T(0)*d(0), ..., T(B-2)*d(B-2) ] per layer, + 1/n and n per node ----
-    DevTmp x0, ntot, dseg;
-    const size_t cnt0 = (size_t)std::max(nl_hist * stride, CH) * npad;
-    HSD_TMP_ALLOC(ctx, x0, cnt0 * ctx->elem_bytes);
-    HSD_TMP_ALLOC(ctx, ntot, (size_t)nsg * npad * sizeof(uint32_t));
-    HSD_TMP_ALLOC(ctx, dseg, sizeof(ctx->seg_begin));
-    HSD_HIP(ctx, hipMemsetAsync(x0.p, 0, cnt0 * ctx->elem_bytes, ctx->stream));
-    HSD_HIP(ctx, hipMemsetAsync(ntot.p, 0, (size_t)nsg * npad * sizeof(uint32_t), ctx->stream));
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_inv, (size_t)nsg * npad))) return rc;
-    {   // padded nodes: inv = 2 (treated as empty rings; never stored) -- filled on the device (no host buffer whose lifetime an
-        // asynchronous copy would depend on; seg_begin lives in the context)
-        hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)(((size_t)nsg * npad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_inv, (int64_t)nsg * npad, 2.0);
-        HSD_HIP(ctx, hipMemcpyAsync(dseg.p, ctx->seg_begin, sizeof(ctx->seg_begin), hipMemcpyHostToDevice, ctx->stream));
-        if (use_u32)
-            hipLaunchKernelGGL(prep_zp_kernel<uint32_t>, grid, block, 0, ctx->stream, p, x0.as<uint32_t>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
-        else
-            hipLaunchKernelGGL(prep_zp_kernel<double>, grid, block, 0, ctx->stream, p, x0.as<double>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    mark("support check + bin columns");
-    HsdSegDesc *tab = ctx->seg_tab;
-    for (int s = 0; s < nl_hist; ++s) tab[s] = HsdSegDesc{s * stride, B, -1, 0, 0, -1};
-    ctx->dcols_alg = nl_hist * B;
-
-    if (!use_u32 || nl_hist == 0) {
-        // fp64 fallback (non-integral support or sums beyond 32 bits): bin form only
-        ctx->d_X = x0.release();
-        ctx->dcols = std::max(nl_hist * stride, CH);
-        ctx->mode = use_u32 ? PAIR_SAD_U32 : PAIR_ZP_F64;
-    } else {
-        // ---- per-column maxima (packing decisions) and per-granule ring maxima (rank form) ----
-        const int ncol32 = nl_hist * stride;
-        const int ngran = (int)(npad / 64);
-        DevTmp cmaxd;
-        HSD_TMP_ALLOC(ctx, cmaxd, (size_t)ncol32 * sizeof(uint32_t));
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax, (size_t)nl_hist * ngran))) return rc;
-        ctx->ngran = ngran;
-        hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)ncol32), dim3(256), 0, ctx->stream, x0.as<uint32_t>(), npad, cmaxd.as<uint32_t>());
-        std::vector<uint32_t> cmax((size_t)ncol32);
-        HSD_HIP(ctx, hipMemcpyAsync(cmax.data(), cmaxd.p, cmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-
-        mark("column maxima");
-        // uint16 packing: two columns per word, one v_sad_u16 covers both.  A column whose values (tail count x bin
-        // width) reach 65536 is split into columns of smaller width (|T_i - T_j| (d1 + d2) is the sum of both parts).
-        const char *e16 = hsd_hook(H_SAD16);
-        bool pack = !(e16 && atoi(e16) == 0);
-        std::vector<int> vsrc;
-        std::vector<uint32_t> vdiv, vmul;
-        for (int r = 0; r < B && pack; ++r) {
-            uint32_t mx = 0;                                   // worst layer decides the split of column r
-            for (int sgi = 0; sgi < nl_hist; ++sgi) mx = std::max(mx, cmax[(size_t)sgi * stride + r]);
-            const double width = r == 0 ? ctx->support[0] : ctx->support[(size_t)r] - ctx->support[(size_t)r - 1];
-            const uint32_t wd = (uint32_t)width;
-            if (mx < 65536u) { vsrc.push_back(r); vdiv.push_back(1u); vmul.push_back(1u); continue; }
-            if (wd == 0) { pack = false; break; }
-            const uint32_t tmax = mx / wd;                      // largest count in this column
-            if (tmax > 65535u) { pack = false; break; }
-            const uint32_t dmax = 65535u / tmax;                // widest part that keeps count * part < 65536
-            for (uint32_t left = wd; left > 0;) {
-                const uint32_t d = std::min(left, dmax);
-                vsrc.push_back(r); vdiv.push_back(wd); vmul.push_back(d);
-                left -= d;
-            }
-        }
-        const int V = (int)vsrc.size();
-        if (pack && V > 4 * B) pack = false;
-        const int bin_words = pack ? (V + 1) / 2 : B;
-        const int bin_stride = (int)round_up(bin_words, CH);
-
-        // Threshold and rank columns per layer.  Candidates: theta = 0 (pure rank form), the bin boundaries that fall on a
-        // word boundary of the packed bin columns nearest to eighths of the support, and bins 2 / 4 / 8 / 16.  For each, the members above theta of
-        // every node -> maxima per 64-node granule -> expected words per tile pair
-        //   low words + E[ rank words if they fit the cap, else the upper bin words ]
-        // over all granule pairs (exact from the sorted maxima); the cheapest candidate is stored, or none if nothing
-        // beats the plain bin form by 3 %.
-        const char *er = hsd_hook(H_RANK);
-        const int rank_mode = er ? atoi(er) : 2;                // 0: bin form only; 1: theta = 0 only; 2: any threshold
-        bool rank_ok = rank_mode != 0;
-        if (pack && ctx->support.back() >= 65536.0) rank_ok = false;      // member values must fit a uint16 half
-        const auto words_of = [&](uint32_t R) { return pack ? (int64_t)((R + 1) / 2) : (int64_t)R; };
-        // first packed word of raw column r (columns are split into virtual ones for packing): word boundary iff even
-        std::vector<int> vfirst((size_t)B + 1, V);
-        if (pack) { for (int v = V - 1; v >= 0; --v) vfirst[(size_t)vsrc[(size_t)v]] = v; vfirst[(size_t)B] = V; }
-        else for (int r = 0; r <= B; ++r) vfirst[(size_t)r] = r;
-        std::vector<int> cand;                                  // raw column index r*: columns [0, r*) stay in bin form
-        cand.push_back(0);
-        if (rank_mode >= 2) {
-            // ... and a few cuts close to the bottom of the support: a ring of ~10 members (ring 1 of a scale-free graph)
-            // is cheapest with its two or three most common small values in bin form and the rest by rank
-            std::vector<int> wanted = {2, 4, 8, 16};
-            for (int e8 = 1; e8 < 8; ++e8) wanted.push_back(std::max(1, e8 * B / 8));
-            std::sort(wanted.begin(), wanted.end());
-            for (int r : wanted) {
-                while (r < B && pack && (vfirst[(size_t)r] & 1)) ++r;     // packed: the cut must fall between two words
-                if (r < B && r > cand.back()) cand.push_back(r);
-            }
-        }
-        const int NC = (int)cand.size();
-        const int ngran16 = (int)(npad / 16);
-        std::vector<uint32_t> gmax16;                           // [nl_hist][NC][ngran16]: members above the candidate threshold, per 16-node granule
-        if (rank_ok) {
-            // column r >= 1 is the interval [s_{r-1}, s_r): members above theta = s_{r*-1} are those in bins >= r*
-            DevTmp dcand, dabove, dgm;
-            HSD_TMP_ALLOC(ctx, dcand, (size_t)NC * sizeof(int));
-            HSD_TMP_ALLOC(ctx, dabove, (size_t)nl_hist * NC * npad * sizeof(uint32_t));
-            HSD_TMP_ALLOC(ctx, dgm, (size_t)nl_hist * NC * ngran16 * sizeof(uint32_t));
-            HSD_HIP(ctx, hipMemcpyAsync(dcand.p, cand.data(), (size_t)NC * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            HSD_HIP(ctx, hipMemsetAsync(dabove.p, 0, (size_t)nl_hist * NC * npad * sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(count_above_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nl_hist), block, 0, ctx->stream, p, dcand.as<int>(), NC,
-                               dabove.as<uint32_t>());
-            hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)(nl_hist * NC)), dim3(256), 0, ctx->stream,
-                               dabove.as<uint32_t>(), npad, ngran16, dgm.as<uint32_t>());
-            gmax16.resize((size_t)nl_hist * NC * ngran16);
-            HSD_HIP(ctx, hipMemcpyAsync(gmax16.data(), dgm.p, gmax16.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // temporaries leave scope
-        }
-        mark("members above candidates");
-        int col = nl_hist * bin_stride;
-        int list_cap = 1;
-        std::vector<int> first_bin((size_t)nl_hist, 0);
-        std::vector<uint32_t> rmax_sel((size_t)nl_hist * ngran, 0u), rmax16_sel((size_t)nl_hist * ngran16, 0u);
-        for (int sgi = 0; sgi < nl_hist; ++sgi) {
-            tab[sgi] = HsdSegDesc{sgi * bin_stride, bin_words, -1, 0, 0, -1};
-            list_cap += (bin_words + CH - 1) / CH + 2;  // either kernel: chunks of CH words; no form of a layer is longer than its bin form
-        }
-        // Tile order and thresholds are chosen together.  A tile side of the persistent kernel is eight 16-node granules that
-        // are consecutive in the graph's granule order; with R(t) the most members above a layer's threshold among a tile's
-        // nodes, a tile pair reads (min form)  low words + ceil(min(R_a, R_b) / 2)  rank words if that fits the cap, else
-        // the upper bin words.  For each candidate order -- the natural one and the granules sorted by one (layer, threshold)
-        // key -- every layer takes its cheapest threshold (expected words over all tile pairs, exact from the sorted tile
-        // maxima); the cheapest total wins.  A layer that does not beat its plain bin form by 3 % keeps that.
-        const int64_t G16 = n / 16;                               // whole granules
-        struct LayerPlan { int q, cap; double cost; };
-        std::vector<int32_t> best_order;
-        std::vector<LayerPlan> best_plan((size_t)nl_hist, LayerPlan{-1, 0, (double)bin_words});
-        double best_total = (double)nl_hist * bin_words;
-        bool best_sorted = false;
-        if (rank_ok && bin_words >= 2 && G16 >= 1) {
-            const char *es = hsd_hook(H_GRAN_SORT);
-            const bool may_sort = !(es && atoi(es) == 0) && G16 >= 16;
-            const int64_t NT = std::max<int64_t>(1, G16 / 8);     // tiles of eight granules (a last, shorter group counts as one)
-            std::vector<int32_t> order((size_t)G16);
-            auto plan_for = [&](const std::vector<int32_t> &ord, std::vector<LayerPlan> &plan) -> double {
-                double total = 0.0;
-                const int64_t nt = (G16 + 7) / 8;
-                std::vector<uint32_t> tm((size_t)nt);             // (per call: candidate orders are evaluated on several host threads)
-                for (int sgi = 0; sgi < nl_hist; ++sgi) {
-                    LayerPlan bp{-1, 0, 0.97 * bin_words};
-                    for (int q = 0; q < NC; ++q) {
-                        const int low_w = vfirst[(size_t)cand[(size_t)q]] / (pack ? 2 : 1), hi_w = bin_words - low_w;
-                        if (hi_w < 2) continue;
-                        const uint32_t *gm = gmax16.data() + ((size_t)sgi * NC + q) * ngran16;
-                        uint32_t gmx = 0;
-                        for (int64_t t = 0; t < nt; ++t) {
-                            uint32_t m = 0;
-                            for (int64_t e = 8 * t; e < std::min<int64_t>(G16, 8 * t + 8); ++e) m = std::max(m, gm[ord[(size_t)e]]);
-                            tm[(size_t)t] = m;
-                            gmx = std::max(gmx, m);
-                        }
-                        if (n % 16) gmx = std::max(gmx, gm[G16]);        // (the partial last granule: one-tile kernel only)
-                        std::sort(tm.begin(), tm.begin() + nt);
-                        const int cap = (int)std::min<int64_t>(hi_w - 1, words_of(gmx));
-                        // E over unordered tile pairs of f(min): the k-th smallest (0-based) is the minimum of nt - k pairs
-                        long double acc = 0.0L;
-                        for (int64_t k2 = 0; k2 < nt; ++k2) {
-                            int64_t wr = words_of(tm[(size_t)k2]);
-                            if (low_w + wr == 0) wr = 1;
-                            acc += (long double)(wr <= cap ? wr : hi_w) * (long double)(nt - k2);
-                        }
-                        const double cost = low_w + (double)(acc / ((long double)nt * (nt + 1) / 2));
-                        if (cost < bp.cost) bp = LayerPlan{q, cap, cost};
-                    }
-                    if (bp.q < 0) bp.cost = bin_words;
-                    plan[(size_t)sgi] = bp;
-                    total += bp.cost;
-                }
-                return total;
-            };
-            (void)NT;
-            for (int64_t g = 0; g < G16; ++g) order[(size_t)g] = (int32_t)g;
-            std::vector<LayerPlan> plan((size_t)nl_hist);
-            best_total = plan_for(order, plan);
-            best_plan = plan;
-            best_order = order;
-            if (may_sort) {
-                // one candidate order per (layer, threshold) key: sorted and priced independently (host threads: 24 orders x 24
-                // (layer, threshold) prices took 13 of the 17.6 ms of a warm hsd_pair_prepare at BA N = 100k on one core), then
-                // compared in the fixed order of the keys
-                const int n_task = nl_hist * NC;
-                std::vector<std::vector<int32_t>> t_order((size_t)n_task);
-                std::vector<std::vector<LayerPlan>> t_plan((size_t)n_task, std::vector<LayerPlan>((size_t)nl_hist));
-                std::vector<double> t_total((size_t)n_task, 0.0);
-                const char *ept = hsd_hook(H_PLAN_THREADS);    // cap of the host threads (1: everything on the calling thread)
-                int thr_cap = ept ? atoi(ept) : 16;
-                if (thr_cap < 1) thr_cap = 1;
-                const int n_thr = std::max(1, std::min<int>(std::min(n_task, thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
-                // tasks are drawn from a shared counter, so whatever threads exist (possibly none but the caller) finish them all
-                std::atomic<int> next_task{0};
-                std::atomic<bool> task_failed{false};            // nothing may leave a thread, or the C ABI, as an exception
-                auto work = [&]() noexcept {
-                    try {
-                        for (int task; (task = next_task.fetch_add(1, std::memory_order_relaxed)) < n_task;) {
-                            const uint32_t *key = gmax16.data() + (size_t)task * ngran16;        // task = ks * NC + kq
-                            std::vector<int32_t> &ord = t_order[(size_t)task];
-                            ord.resize((size_t)G16);
-                            for (int64_t g = 0; g < G16; ++g) ord[(size_t)g] = (int32_t)g;
-                            std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
-                            t_total[(size_t)task] = plan_for(ord, t_plan[(size_t)task]);
-                        }
-                    } catch (...) { task_failed.store(true); }
-                };
-                {
-                    std::vector<std::thread> pool;
-                    try {
-                        pool.reserve((size_t)n_thr);
-                        const char *eft = hsd_hook(H_PLAN_THREADS_FAIL);       // test hook: creating the t-th thread fails
-                        const int fail_at = eft ? atoi(eft) : 0;
-                        for (int t = 1; t < n_thr; ++t) {
-                            if (t == fail_at) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
-                            pool.emplace_back(work);
-                        }
-                    } catch (...) {
-                        // RLIMIT_NPROC / a pids limit: the threads that exist and the caller share the tasks
-                    }
-                    work();
-                    for (auto &th : pool) th.join();
-                }
-                if (task_failed.load()) return hsd_fail(ctx, HSD_ERR_NOMEM, "hsd_pair_prepare: out of host memory while pricing the granule orders");
-                for (int task = 0; task < n_task; ++task)
-                    if (t_total[(size_t)task] < 0.99 * best_total) {
-                        best_total = t_total[(size_t)task]; best_plan = t_plan[(size_t)task]; best_order = t_order[(size_t)task]; best_sorted = true;
-                    }
-            }
-        }
-        mark("order + thresholds (host)");
-        ctx->gran_order.clear();
-        if (best_sorted) ctx->gran_order = best_order;
-        int suf_rows = 1;                                         // row 0: zeros
-        const char *e8 = hsd_hook(H_U8);
-        const bool u8_ok = !(e8 && atoi(e8) == 0);               // HSD_U8=0: no uint8 ranges (tests: same bits either way)
-        std::vector<int> r8_reserved((size_t)nl_hist, -1);
-        for (int sgi = 0; sgi < nl_hist; ++sgi) {
-            const LayerPlan &bp = best_plan[(size_t)sgi];
-            if (bp.q < 0) continue;
-            const int low_w = vfirst[(size_t)cand[(size_t)bp.q]] / (pack ? 2 : 1);
-            tab[sgi].rank_col0 = col;
-            tab[sgi].rank_low = low_w;
-            tab[sgi].rank_cap = bp.cap;
-            tab[sgi].suf_row0 = suf_rows;
-            suf_rows += bp.cap + 1;
-            first_bin[(size_t)sgi] = cand[(size_t)bp.q];
-            const uint32_t *gm = gmax16.data() + ((size_t)sgi * NC + bp.q) * ngran16;
-            std::copy(gm, gm + ngran16, rmax16_sel.begin() + (size_t)sgi * ngran16);
-            for (int g = 0; g < ngran; ++g)                        // the one-tile kernel plans from 64-node granules in natural order
-                rmax_sel[(size_t)sgi * ngran + g] = std::max(std::max(gm[4 * g], gm[4 * g + 1]), std::max(gm[4 * g + 2], gm[4 * g + 3]));
-            col += (int)round_up(low_w + bp.cap, CH);
-            if (pack && u8_ok) { r8_reserved[(size_t)sgi] = col; col += (int)round_up(low_w + bp.cap + 1, CH); }
-        }
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax16, (size_t)nl_hist * ngran16))) return rc;
-        ctx->ngran16 = ngran16;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_suf, (size_t)(suf_rows + 1) * npad))) return rc;
-        ctx->suf_rows = suf_rows;
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_suf, 0, (size_t)(suf_rows + 1) * npad * sizeof(uint32_t), ctx->stream));
-        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax, rmax_sel.data(), rmax_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax16, rmax16_sel.data(), rmax16_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // rmax_sel / rmax16_sel are locals
-        if (hsd_hook(H_PLAN_VERBOSE)) {
-            fprintf(stderr, "[hsd plan] %s granule order, expected words per tile pair %.1f (bin form %d per layer):", best_sorted ? "sorted" : "natural", best_total,
-                    bin_words);
-            for (int sgi = 0; sgi < nl_hist; ++sgi)
-                fprintf(stderr, " layer %d: first rank bin %d, low %d, cap %d, %.1f;", sgi, first_bin[(size_t)sgi], tab[sgi].rank_low, tab[sgi].rank_cap,
-                        best_plan[(size_t)sgi].cost);
-            fprintf(stderr, "\n");
-        }
-        ctx->list_cap = list_cap;
-        ctx->dcols = std::max(col, CH);
-        ctx->dcols_alg = nl_hist * bin_words;
-
-        const size_t cntf = (size_t)ctx->dcols * npad;
-        HSD_HIP(ctx, hipMalloc(&ctx->d_X, cntf * sizeof(uint32_t)));
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cntf * sizeof(uint32_t), ctx->stream));
-        if (pack) {
-            DevTmp dv;
-            HSD_TMP_ALLOC(ctx, dv, (size_t)V * 3 * sizeof(uint32_t));
-            uint32_t *d_vsrc = dv.as<uint32_t>(), *d_vdiv = d_vsrc + V, *d_vmul = d_vdiv + V;
-            HSD_HIP(ctx, hipMemcpyAsync(d_vsrc, vsrc.data(), (size_t)V * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            HSD_HIP(ctx, hipMemcpyAsync(d_vdiv, vdiv.data(), (size_t)V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            HSD_HIP(ctx, hipMemcpyAsync(d_vmul, vmul.data(), (size_t)V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(pack_u16_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)nl_hist), dim3(256), 0, ctx->stream,
-                               x0.as<uint32_t>(), npad, nl_hist, stride, V, reinterpret_cast<const int *>(d_vsrc), d_vdiv, d_vmul, bin_stride,
-                               (uint32_t *)ctx->d_X);
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dv leaves scope
-            ctx->seg_valid16 = bin_words;
-            ctx->mode = PAIR_SAD_U16;
-        } else {
-            for (int sgi = 0; sgi < nl_hist; ++sgi)
-                HSD_HIP(ctx, hipMemcpyAsync((uint32_t *)ctx->d_X + (size_t)sgi * bin_stride * npad, x0.as<uint32_t>() + (size_t)sgi * stride * npad,
-                                            (size_t)B * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            ctx->mode = PAIR_SAD_U32;
-        }
-        mark("operand matrix + packing");
-        for (int s = 0; s <= nl_hist; ++s) ctx->seg_begin[s] = s * bin_stride;
-        bool any_rank = false;
-        for (int sgi = 0; sgi < nl_hist; ++sgi) any_rank |= tab[sgi].rank_col0 >= 0;
-        if (any_rank) {
-            DevTmp dr;
-            std::vector<int> rc0((size_t)4 * nl_hist);
-            for (int sgi = 0; sgi < nl_hist; ++sgi) {
-                rc0[(size_t)sgi] = tab[sgi].rank_col0 < 0 ? -1 : tab[sgi].rank_col0 + tab[sgi].rank_low;
-                rc0[(size_t)nl_hist + sgi] = tab[sgi].rank_cap;
-                rc0[(size_t)2 * nl_hist + sgi] = first_bin[(size_t)sgi];
-                rc0[(size_t)3 * nl_hist + sgi] = tab[sgi].suf_row0;
-                if (tab[sgi].rank_col0 >= 0 && tab[sgi].rank_low > 0)       // the bin columns below the threshold, once more in front of the ranks
-                    HSD_HIP(ctx, hipMemcpyAsync((uint32_t *)ctx->d_X + (size_t)tab[sgi].rank_col0 * npad, (uint32_t *)ctx->d_X + (size_t)tab[sgi].bin_col0 * npad,
-                                                (size_t)tab[sgi].rank_low * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            }
-            HSD_TMP_ALLOC(ctx, dr, rc0.size() * sizeof(int));
-            HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), rc0.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)nl_hist);
-            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
-            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
-        }
-        mark("rank columns + suffix sums");
-        // ---- uint8 ranges (persistent kernel).  Most values of a rank-form range are small: ring 2 of a scale-free graph has a
-        // handful of hubs in front of hundreds of ordinary members, and its tail counts fall below 256 a few bins up.  v_sad_u8
-        // takes four such columns per instruction where v_sad_u16 takes two.  Per layer: keep the first b8 low-bin words and the
-        // first r16 rank words as they are and store the rest two-words-into-one as bytes; a tile may read that range when none
-        // of its nodes holds a value >= 256 in the byte part (flag in bit 31 of its granules' maxima).  (b8, r16) by expected
-        // words over all tile pairs in the chosen order, exact from the sorted tile maxima of the tiles that qualify.
-        for (int sgi = 0; sgi < nl_hist && pack && u8_ok; ++sgi) {
-            if (tab[sgi].rank_col0 < 0 || r8_reserved[(size_t)sgi] < 0 || G16 < 8) continue;
-            const int low = tab[sgi].rank_low, cap = tab[sgi].rank_cap;
-            DevTmp dneed, dgn;
-            HSD_TMP_ALLOC(ctx, dneed, (size_t)2 * npad * sizeof(uint32_t));
-            HSD_TMP_ALLOC(ctx, dgn, (size_t)2 * ngran16 * sizeof(uint32_t));
-            HSD_HIP(ctx, hipMemsetAsync(dneed.p, 0, (size_t)2 * npad * sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(u8_need_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, tab[sgi],
-                               dneed.as<uint32_t>());
-            hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), 2u), dim3(256), 0, ctx->stream, dneed.as<uint32_t>(), npad, ngran16,
-                               dgn.as<uint32_t>());
-            std::vector<uint32_t> gneed((size_t)2 * ngran16);
-            HSD_HIP(ctx, hipMemcpyAsync(gneed.data(), dgn.p, gneed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const uint32_t *gb8 = gneed.data(), *gr8 = gneed.data() + ngran16;
-            uint32_t *gR = rmax16_sel.data() + (size_t)sgi * ngran16;
-            const int64_t nt = (G16 + 7) / 8;
-            std::vector<uint32_t> tb8((size_t)nt, 0u), tr8((size_t)nt, 0u), tR((size_t)nt, 0u);
-            for (int64_t t = 0; t < nt; ++t)
-                for (int64_t e = 8 * t; e < std::min<int64_t>(G16, 8 * t + 8); ++e) {
-                    const int64_t g = ctx->gran_order.empty() ? e : ctx->gran_order[(size_t)e];
-                    tb8[(size_t)t] = std::max(tb8[(size_t)t], gb8[g]);
-                    tr8[(size_t)t] = std::max(tr8[(size_t)t], gr8[g]);
-                    tR[(size_t)t] = std::max(tR[(size_t)t], gR[g]);
-                }
-            std::vector<int> cb, cr;
-            for (int v : {0, 2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 64}) if (v < low) cb.push_back(v);
-            cb.push_back(low);
-            for (int v : {0, 1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32, 48}) if (v < cap) cr.push_back(v);
-            cr.push_back(cap);
-            double best_save = 0.0;
-            int best_b = -1, best_r = -1;
-            std::vector<int64_t> wrs;
-            for (int b8 : cb)
-                for (int r16 : cr) {
-                    const int fixed = b8 + r16 + (low - b8 + 1) / 2;
-                    wrs.clear();
-                    for (int64_t t = 0; t < nt; ++t)
-                        if ((int)tb8[(size_t)t] <= b8 && (int)tr8[(size_t)t] <= r16) wrs.push_back(words_of(tR[(size_t)t]));
-                    std::sort(wrs.begin(), wrs.end());
-                    long double save = 0.0L;
-                    const int64_t m = (int64_t)wrs.size();
-                    for (int64_t k2 = 0; k2 < m; ++k2) {
-                        int64_t wr = wrs[(size_t)k2];
-                        if (low + wr == 0) wr = 1;
-                        if (wr > cap) break;
-                        const int64_t c16 = low + wr, c8 = fixed + std::max<int64_t>(wr - r16, 0) / 2 + (std::max<int64_t>(wr - r16, 0) & 1);
-                        if (c8 >= 1 && c8 < c16) save += (long double)(c16 - c8) * (long double)(m - k2);
-                    }
-                    const double sv = (double)(save / ((long double)nt * (nt + 1) / 2));
-                    if (sv > best_save) { best_save = sv; best_b = b8; best_r = r16; }
-                }
-            if (best_b < 0 || best_save < 0.5) continue;
-            HsdSegDesc &d = tab[sgi];
-            d.r8_col0 = r8_reserved[(size_t)sgi];
-            d.r8_k16 = best_b + best_r;
-            d.r8_fixed = d.r8_k16 + (low - best_b + 1) / 2;
-            d.r8_r16 = best_r;
-            d.r8_cap = (cap - best_r + 1) / 2;
-            uint32_t *X = (uint32_t *)ctx->d_X;
-            if (best_b > 0)
-                HSD_HIP(ctx, hipMemcpyAsync(X + (size_t)d.r8_col0 * npad, X + (size_t)d.rank_col0 * npad, (size_t)best_b * npad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            if (best_r > 0)
-                HSD_HIP(ctx, hipMemcpyAsync(X + (size_t)(d.r8_col0 + best_b) * npad, X + (size_t)(d.rank_col0 + low) * npad, (size_t)best_r * npad * sizeof(uint32_t),
-                                            hipMemcpyDeviceToDevice, ctx->stream));
-            const int nb8 = (low - best_b + 1) / 2;
-            if (nb8 > 0)
-                hipLaunchKernelGGL(pack_u8_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)nb8), dim3(256), 0, ctx->stream, X, npad, d.rank_col0 + best_b,
-                                   low - best_b, d.r8_col0 + d.r8_k16, nb8);
-            if (d.r8_cap > 0)
-                hipLaunchKernelGGL(pack_u8_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)d.r8_cap), dim3(256), 0, ctx->stream, X, npad,
-                                   d.rank_col0 + low + best_r, cap - best_r, d.r8_col0 + d.r8_fixed, d.r8_cap);
-            for (int g = 0; g < ngran16; ++g)
-                if ((int)gb8[g] > best_b || (int)gr8[g] > best_r) gR[g] |= 0x80000000u;
-            HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax16 + (size_t)sgi * ngran16, gR, (size_t)ngran16 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // gR (rmax16_sel) / temporaries
-            if (hsd_hook(H_PLAN_VERBOSE))
-                fprintf(stderr, "[hsd plan] layer %d uint8 range: %d low-bin + %d rank words stay uint16, %d + up to %d words of bytes; saves %.1f words per tile pair\n", sgi,
-                        best_b, best_r, nb8, d.r8_cap, best_save);
-        }
-    }
-    mark("byte ranges");
-    if (ctx->mode == PAIR_ZP_F64 || nl_hist == 0 || ctx->list_cap == 0) {
-        ctx->list_cap = 1;
-        for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + CH - 1) / CH + 2;
-    }
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
-    HSD_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tab, tab, (size_t)nsg * sizeof(HsdSegDesc), hipMemcpyHostToDevice, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));              // x0 / ntot / dseg leave scope
-    return HSD_OK;
-}
-
-// ring 0 = {i}: its histogram is the point mass at node_bin[i] -- unless the caller uploaded other counts (hsd_signature_set_counts); flag bit 2 then
-__global__ void kl_point_kernel(PrepArgs p, double *__restrict__ point) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + (int64_t)i * p.L * p.B;
-    uint32_t tot = 0;
-    for (int b = 0; b < p.B; ++b) tot += c[b];
-    const int nb = p.node_bin[i];
-    if (tot != 1u || c[nb] != 1u) atomicOr(p.flag + 1, 4);
-    point[i] = (double)nb;
-}
-
-// KL of layer 0 in closed form.  Ring 0 of node i is the point mass at its own bin b_i, so on the smoothed support
-// P_i(b) = ([b == b_i] + alpha) / Z, Z = 1 + alpha B, and sum_b P_i log(P_i / P_j) has two values only:
-//   0 where b_i == b_j, and  ((1 + alpha) - alpha) (log((1 + alpha) / Z) - log(alpha / Z)) / Z = log((1 + alpha) / alpha) / Z  elsewhere
-// -- the same both ways (so the symmetric form adds the same constant), and sorted histograms (kl_sorted) of two point masses are
-// equal: nothing to add.  The B dense columns of that layer (a sixth of config 3's arithmetic, a quarter at K = 3) become one compare
-// per pair in the tile epilogue, where W1 adds its own ring-0 term |v_i - v_j|.  HSD_KL_POINT=0: layer 0 stays in the dense loop.
-int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metric, double kl_alpha, int kl_sorted) {
-    const int64_t n = p.n, npad = p.npad;
-    const int B = p.B, L = p.L;
-    const int sym = metric == HSD_METRIC_SYMMETRIC_KL;
-    constexpr int CH = chunk_cols(K_DOT);
-    ctx->has_point = false;
-    ctx->kl_point_c = 0.0;
-    bool closed = p.layer_lo == 0 && nl >= 2 && kl_alpha > 0.0 && hsd_hook_int(H_KL_POINT, 1) != 0;
-    if (closed) {
-        // (d_H holds two vectors for the KL kinds: the entropy term [npad], then the ring-0 values [npad])
-        hipLaunchKernelGGL(kl_point_kernel, dim3(grid.x), block, 0, ctx->stream, p, ctx->d_H + npad);
-        int flag[4] = {0, 0, 0, 0};
-        HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag + 1, 0, sizeof(int), ctx->stream));
-        if (flag[1] & 4) closed = false;            // ring 0 is not the node itself somewhere (caller-assigned rings): the dense loop
-    }
-    if (closed) {
-        p.layer_lo = 1;
-        nl -= 1;
-        grid.y = (unsigned)nl;
-        if (!kl_sorted) {
-            ctx->has_point = true;
-            ctx->kl_point_c = (log((1.0 + kl_alpha) / kl_alpha)) / (1.0 + kl_alpha * (double)B);
-        }
-    }
-    const int half = (int)round_up((int64_t)nl * B, CH);
-    ctx->dcols = sym ? 2 * half : half;
-    ctx->dcols_alg = (sym ? 2 : 1) * nl * B;
-    ctx->elem_bytes = 8;
-    const size_t cnt = (size_t)ctx->dcols * npad;
-    HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
-    HSD_HIP(ctx, hipMalloc(&ctx->d_Y, cnt * sizeof(double)));
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_Y, 0, cnt * sizeof(double), ctx->stream));
-    DevTmp hpart, sorted;
-    HSD_TMP_ALLOC(ctx, hpart, (size_t)nl * npad * sizeof(double));
-    if (kl_sorted) {
-        int Bp2 = 1;
-        while (Bp2 < B) Bp2 <<= 1;
-        HSD_TMP_ALLOC(ctx, sorted, (size_t)n * L * B * sizeof(uint32_t));
-        hipLaunchKernelGGL(sort_counts_kernel, dim3((unsigned)(n * L)), dim3(std::min(256, std::max(64, Bp2 / 2))),
-                           (size_t)Bp2 * sizeof(uint32_t), ctx->stream, ctx->d_counts, sorted.as<uint32_t>(), B, Bp2);
-        p.counts = sorted.as<uint32_t>();
-    }
-    hipLaunchKernelGGL(prep_kl_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
-                       (double *)ctx->d_Y, hpart.as<double>());
-    hipLaunchKernelGGL(sum_layers_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, hpart.as<double>(), nl, npad, n, ctx->d_H);
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));              // temporaries leave scope
-    ctx->mode = sym ? PAIR_SKL : PAIR_KL;
-    ctx->n_seg = 0;
-    return HSD_OK;
-}
-
-int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int layer_hi, double kl_alpha, int kl_sorted) {
-    const int64_t n = ctx->n;
-    const int L = ctx->hop + 1, B = ctx->n_bins;
-    const int64_t npad = round_up(n + HSD_TILE, HSD_TILE);
-    ctx->npad = npad;
-    ctx->list_cap = 0;
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
-    PrepArgs p{ctx->d_counts, ctx->d_support, ctx->d_node_bin, n, npad, L, B, layer_lo, layer_hi, ctx->d_flag};
-    const int nl = layer_hi - layer_lo + 1;
-    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nl), block(256);
-    int rc;
-    // d_H: per-node entropy term (KL) or the ring-0 point values (W1 with layer 0)
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)2 * npad))) return rc;
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)2 * npad * sizeof(double), ctx->stream));
-    if (metric == HSD_METRIC_WASSERSTEIN) {
-        const int nl_hist = nl - (layer_lo == 0 ? 1 : 0);
-        rc = align == HSD_ALIGN_NONE ? prepare_w1_raw(ctx, p, grid, block, nl_hist) : prepare_w1_zeropad(ctx, p, grid, block, nl_hist);
-        ctx->d_Y = nullptr;
-    } else {
-        rc = prepare_kl(ctx, p, grid, block, nl, metric, kl_alpha, kl_sorted);
-    }
-    if (rc) return rc;
-    int flag[4] = {0, 0, 0, 0};
-    HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    HSD_HIP(ctx, hipGetLastError());
-    // ring-0 point values in use? (W1: d_H is the point array; KL: prepare_kl decided, the point array follows the entropy term)
-    if (metric == HSD_METRIC_WASSERSTEIN) ctx->has_point = layer_lo == 0;
-    if (metric == HSD_METRIC_WASSERSTEIN && align == HSD_ALIGN_NONE && (flag[0] & 1))
-        return hsd_fail(ctx, HSD_ERR_EMPTY_RING, "Distribution can't be empty.");
-    if (metric != HSD_METRIC_WASSERSTEIN && (flag[0] & 2))
-        return hsd_fail(ctx, HSD_ERR_NOT_NORMALISED, "The sum of probability distribution must be 1.0.");
-    return HSD_OK;
-}
-
-}  // namespace
-
-extern "C" int hsd_pair_prepare(hsd_ctx *ctx, int metric, int align, int layer_lo, int layer_hi, double kl_alpha,
-                                int kl_sorted) try {
-    HSD_CHECK_CTX(ctx);
-    if (!ctx->d_counts) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "no signature built");
-    if (layer_lo < 0 || layer_hi > ctx->hop || layer_lo > layer_hi)
-        return hsd_fail(ctx, HSD_ERR_INVALID, "layers [%d,%d] outside [0,%d]", layer_lo, layer_hi, ctx->hop);
-    if (metric != HSD_METRIC_WASSERSTEIN && metric != HSD_METRIC_KL && metric != HSD_METRIC_SYMMETRIC_KL)
-        return hsd_fail(ctx, HSD_ERR_UNSUPPORTED, "metric %d is not implemented.", metric);
-    if (align != HSD_ALIGN_NONE && align != HSD_ALIGN_ZEROPAD) return hsd_fail(ctx, HSD_ERR_INVALID, "bad align %d", align);
-    if (!(kl_alpha >= 0.0)) return hsd_fail(ctx, HSD_ERR_INVALID, "kl_alpha must be >= 0");
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hsd_release_operands(ctx);
-    // a failure on any path leaves no half-built operands behind (mode stays PAIR_NONE)
-    const int rc = pair_prepare_impl(ctx, metric, align, layer_lo, layer_hi, kl_alpha, kl_sorted);
-    if (rc != HSD_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        hsd_release_operands(ctx);
-    }
-    return rc;
-} HSD_ABI_GUARD(ctx)
-
-extern "C" int hsd_pair_operand_dims(hsd_ctx *ctx, int *n_columns, int *bytes_per_element) try {
-    HSD_CHECK_CTX(ctx);
-    if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    if (n_columns) *n_columns = ctx->dcols_alg + (ctx->has_point ? 1 : 0);
-    if (bytes_per_element) *bytes_per_element = ctx->elem_bytes;
-    return HSD_OK;
-} HSD_ABI_GUARD(ctx)
-
-extern "C" int hsd_pair_work(hsd_ctx *ctx, double *column_pairs) try {
-    HSD_CHECK_CTX(ctx);
-    if (!column_pairs) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
-    unsigned long long w = 0;
-    HSD_HIP(ctx, hipMemcpyAsync(&w, ctx->d_work, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *column_pairs = (double)w;
-    return HSD_OK;
-} HSD_ABI_GUARD(ctx)
-
-// Row blocks of EQUAL PLANNED COST for `world` ranks (boundaries on whole 128-node tiles): rank g's rows of the prepared distance.
-// The zero-pad kinds read min(R_I, R_J) rank words per tile pair, so a block of hub rows (the first rows of a preferential-attachment
-// graph) costs more per row than a block of leaves: with equal heights the first of 8 ranks took 3.27 ms where the others took 2.8 - 2.95
-// (BA N = 100k, tools_dev/strong_share.py).  Cost of a row tile = sum over the column tiles of (words the planner would read + 32): the
-// 32 stand for what a tile pair costs besides its operand words (folds, stores, hand-over), fitted on those per-rank times.  Kinds whose
-// tiles all cost the same (raw fp64 W1, KL) get equal blocks.  Every rank computes the same partition from the same resident data.
-extern "C" int hsd_pair_shard(hsd_ctx *ctx, int world, int rank, int64_t *r0, int64_t *r1) try {
-    HSD_CHECK_CTX(ctx);
-    if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    if (world < 1 || rank < 0 || rank >= world || !r0 || !r1) return hsd_fail(ctx, HSD_ERR_INVALID, "hsd_pair_shard: bad world / rank %d / %d", world, rank);
-    const int64_t n = ctx->n, T = (n + 127) / 128;
-    std::vector<double> cost((size_t)T, 1.0);
-    const bool seg = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->d_rmax16 && ctx->n_seg > 0 && ctx->n_seg <= 4 && ctx->ngran16 > 0;
-    const char *eb = hsd_hook(H_SHARD_BALANCE);          // 0: equal heights whatever the kind (A/B measurements)
-    const bool balanced = seg && world > 1 && !(eb && atoi(eb) == 0);
-    if (balanced) {
-        const int S = ctx->n_seg, G = ctx->ngran16;
-        std::vector<uint32_t> rm((size_t)S * G);
-        HSD_HIP(ctx, hipMemcpyAsync(rm.data(), ctx->d_rmax16, rm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const auto tile_max = [&](int s, const int32_t *gl, int cnt) {
-            uint32_t m = 0, wide = 0;
-            for (int e = 0; e < cnt; ++e) { const uint32_t v = rm[(size_t)s * G + gl[e]]; m = std::max(m, v & 0x7fffffffu); wide |= v & 0x80000000u; }
-            return m | wide;
-        };
-        // row side: natural tiles (a block's own composition is chosen after the partition); column side: the tiles of the whole graph
-        // in the order the plan chose -- what counts is the distribution of their maxima
-        std::vector<uint32_t> RI((size_t)S * T), RJ;
-        std::vector<int32_t> nat(8);
-        for (int64_t t = 0; t < T; ++t) {
-            int cnt = 0;
-            for (int e = 0; e < 8; ++e) if (8 * t + e < G) nat[(size_t)cnt++] = (int32_t)(8 * t + e);
-            for (int s = 0; s < S; ++s) RI[(size_t)s * T + t] = tile_max(s, nat.data(), cnt);
-        }
-        int64_t TJ = T;
-        const char *es = hsd_hook(H_GRAN_SORT);
-        if (!ctx->gran_order.empty() && !(es && atoi(es) == 0)) {
-            TJ = (int64_t)ctx->gran_order.size() / 8;
-            RJ.resize((size_t)S * TJ);
-            for (int64_t t = 0; t < TJ; ++t)
-                for (int s = 0; s < S; ++s) RJ[(size_t)s * TJ + t] = tile_max(s, ctx->gran_order.data() + 8 * t, 8);
-        } else RJ = RI;
-        const bool pack = ctx->mode == PAIR_SAD_U16;
-        for (int64_t t = 0; t < T; ++t) {
-            double c = 0.0;
-            for (int64_t u = 0; u < TJ; ++u) {
-                int w = 32;
-                for (int s = 0; s < S; ++s) {
-                    const uint32_t a = RI[(size_t)s * T + t], b = RJ[(size_t)s * TJ + u];
-                    w += pack ? choose_segment_form<true>(ctx->seg_tab[s], true, a, b).words : choose_segment_form<false>(ctx->seg_tab[s], true, a, b).words;
-                }
-                c += w;
-            }
-            const int64_t rows = std::min<int64_t>(128, n - 128 * t);
-            cost[(size_t)t] = c * (double)rows / 128.0;
-        }
-    } else cost[(size_t)T - 1] *= (double)(n - 128 * (T - 1)) / 128.0;
-    std::vector<double> pre((size_t)T + 1, 0.0);
-    for (int64_t t = 0; t < T; ++t) pre[(size_t)t + 1] = pre[(size_t)t] + cost[(size_t)t];
-    const auto boundary = [&](int g) -> int64_t {           // first tile of rank g
-        if (g <= 0) return 0;
-        if (g >= world) return T;
-        const double want = pre[(size_t)T] * (double)g / (double)world;
-        int64_t b = std::lower_bound(pre.begin(), pre.end(), want) - pre.begin();
-        // (the tile boundary nearest to the target)
-        if (b > 0 && want - pre[(size_t)b - 1] < pre[(size_t)std::min<int64_t>(b, T)] - want) --b;
-        return std::min<int64_t>(std::max<int64_t>(b, 0), T);
-    };
-    int64_t a = boundary(rank), b = boundary(rank + 1);
-    if (b < a) b = a;
-    *r0 = std::min(n, a * 128);
-    *r1 = std::min(n, b * 128);
-    return HSD_OK;
-} HSD_ABI_GUARD(ctx)
+}  // namespace hsd_pair
 
 extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, int64_t ld, int out_on_device) try {
     HSD_CHECK_CTX(ctx);
@@ -3620,711 +2244,3 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
     return HSD_OK;
 } HSD_ABI_GUARD(ctx)
 
-// ------------------------------------------------------------------------------------------
-// Fused k-nearest-neighbour consumer: what KNN_evaluate(dists,
-// metric="precomputed") (main.py:29, tools/evaluate.py:61-69) needs from the distance matrix,
-// without ever writing the N^2 matrix.
-//   1. threshold: D[rows, first M columns] -> tau_i = k-th smallest per row (an upper bound)
-//   2. sweep    : the normal tile kernel; its epilogue appends (j, v) with v <= tau_i to row i
-//   3. select   : per row the k smallest (value, index) candidates
-// Retries with a larger subset / capacity if a candidate list overflowed (heavy ties).
-// ------------------------------------------------------------------------------------------
-// Pruned k-nearest sweep (raw fp64 W1 -- Variant A -- over the whole graph).  The unpruned sweep evaluates every tile pair: 2 x 721 fp64
-// instructions per pair, 215 ms at BA N = 100k, although under the true k-th-nearest thresholds an exact lower bound excludes 96 % of the
-// PAIRS (tools_dev/sim/prune_pairlevel.py).  Tiles of 128 consecutive nodes are too mixed for that bound to exclude a single TILE pair; tiles
-// of 128 SIMILAR nodes are not (tools_dev/sim/prune_sim_a.py: 47 % of the tile pairs survive the first thresholds, 37 % tightened ones).
-// So this consumer -- which writes no matrix and is therefore free to order the nodes as it likes -- works on a node-PERMUTED copy of the
-// operands:
-//   features   per node, the sum of each layer's columns (|difference| = |mean_i - mean_j| of the ring's values, a lower bound of that
-//              layer's W1; any grouping of the columns bounds an L1 distance from below) and the ring-0 value: tk_feature_kernel
-//   order      a k-d order of the nodes on those features (host: median splits along the widest feature down to 128-node leaves)
-//   operands   Xp[c][position] = X[c][node at that position], padded with zero columns to a whole number of tiles: no strips; the
-//              padding positions never enter a list (orig_of < 0)
-//   launch 0   the tile pairs (t, t) and (t, t + 1) under thresholds of +inf: every row collects the ~383 nodes next to it in the order --
-//              its most similar ones -- and the first compaction leaves a threshold within a small factor of the true one (the sampled
-//              columns of the unpruned sweep give the 2 % quantile of a row)
-//   launches   the usual anti-diagonal phases, each filtered on the device (tk_filter_kernel) against the thresholds of the moment
-// The candidate lists hold ORIGINAL node ids (ties are broken by them), the rows are un-permuted at the end: the result is the one the
-// unpruned sweep gives, bit for bit (tests/test_gpu_topk.py).  HSD_TOPK_PRUNE=0 / 1: never / whenever the kind allows.
-// ------------------------------------------------------------------------------------------
-namespace {
-
-// k-d order of the nodes on nf features F[f][i]: split the widest feature at the median (rounded to whole leaves), down to 128-node leaves; ties by
-// node id.  Node-major copy of the features (one node's features in one cache line); once the ranges are short enough their subtrees go to host
-// threads (disjoint ranges of idx: no sharing; a thread that cannot be created leaves its range to the caller, as in hsd_pair_prepare).
-void kd_order_host(const std::vector<double> &F, int64_t n, int nf, std::vector<int32_t> &idx) {
-    idx.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int32_t)i;
-    std::vector<double> A((size_t)n * nf);
-    for (int f = 0; f < nf; ++f)
-        for (int64_t i = 0; i < n; ++i) A[(size_t)i * nf + f] = F[(size_t)f * n + i];
-    const double *Ap = A.data();
-    int32_t *ip = idx.data();
-    const auto split = [Ap, ip, nf](int64_t lo, int64_t hi) -> int64_t {       // returns the split point, or -1 for a leaf
-        if (hi - lo <= 128) return -1;
-        int best = 0;
-        double ext = -1.0;
-        for (int f = 0; f < nf; ++f) {
-            double mn = INFINITY, mx = -INFINITY;
-            for (int64_t q = lo; q < hi; ++q) { const double v = Ap[(size_t)ip[q] * nf + f]; mn = std::min(mn, v); mx = std::max(mx, v); }
-            if (mx - mn > ext) { ext = mx - mn; best = f; }
-        }
-        int64_t mid = lo + ((hi - lo) / 2 + 127) / 128 * 128;
-        if (mid >= hi) mid = lo + (hi - lo) / 2;
-        std::nth_element(ip + lo, ip + mid, ip + hi, [Ap, nf, best](int32_t x, int32_t y) {
-            const double a = Ap[(size_t)x * nf + best], b = Ap[(size_t)y * nf + best];
-            return a < b || (a == b && x < y);
-        });
-        return mid;
-    };
-    const auto subtree = [&split](int64_t lo0, int64_t hi0) noexcept {
-        try {
-            std::vector<std::pair<int64_t, int64_t>> todo{{lo0, hi0}};
-            while (!todo.empty()) {
-                const auto [lo, hi] = todo.back();
-                todo.pop_back();
-                const int64_t mid = split(lo, hi);
-                if (mid < 0) continue;
-                todo.push_back({lo, mid});
-                todo.push_back({mid, hi});
-            }
-        } catch (...) {}                     // (out of memory for the work list: the range stays as it is -- a worse order, the same results)
-    };
-    // A shared work list: a range longer than 4 096 nodes is split by whoever takes it and its halves go back on the list; shorter ones are finished
-    // on the spot.  (Splitting the top of the tree on one thread first -- four full passes over the nodes -- took 7 of the 10 ms of the setup.)
-    const int thr_cap = std::max(1, hsd_hook_int(H_PLAN_THREADS, 16));
-    const int n_thr = std::max(1, std::min<int>(thr_cap, std::max(1, (int)std::thread::hardware_concurrency())));
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<std::pair<int64_t, int64_t>> list{{0, n}};
-    int busy = 0;                                    // ranges taken and not yet finished (their halves may still arrive)
-    const auto work = [&]() noexcept {
-        for (;;) {
-            std::pair<int64_t, int64_t> r;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !list.empty() || busy == 0; });
-                if (list.empty()) return;            // nothing listed, nobody splitting: done
-                r = list.back();
-                list.pop_back();
-                ++busy;
-            }
-            if (r.second - r.first <= 4096) subtree(r.first, r.second);
-            else {
-                const int64_t mid = split(r.first, r.second);
-                if (mid >= 0) {
-                    std::lock_guard<std::mutex> lk(mu);
-                    try { list.push_back({r.first, mid}); list.push_back({mid, r.second}); } catch (...) {}      // (no memory: a worse order, the same results)
-                }
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                --busy;
-            }
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> pool;
-    try {
-        pool.reserve((size_t)n_thr);
-        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
-    } catch (...) {}
-    work();
-    for (auto &th : pool) th.join();
-}
-
-// zero-pad kinds: F[s][i] = the sum of layer s's bin-form columns of node i = the sum of the ring's member values (|su_i - su_j| <= S_s(i, j))
-template <bool PACK>
-__global__ void tk_feature_seg_kernel(const uint32_t *__restrict__ X, int64_t npad, int64_t n, const HsdSegDesc *__restrict__ tab, double *__restrict__ F) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const HsdSegDesc d = tab[blockIdx.y];
-    double t = 0.0;
-    for (int w = 0; w < d.bin_words; ++w) {
-        const uint32_t v = X[(int64_t)(d.bin_col0 + w) * npad + i];
-        t += PACK ? (double)((v & 0xffffu) + (v >> 16)) : (double)v;
-    }
-    F[(int64_t)blockIdx.y * n + i] = t;
-}
-
-// Up[c][p] = U[c][orig[p]] (0 at padding positions), 32-bit words; blockIdx.y = column / row
-__global__ void tk_gather_u32_kernel(const uint32_t *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, uint32_t *__restrict__ Xp) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npad) return;
-    const int32_t o = orig[p];
-    const int64_t c = blockIdx.y;
-    Xp[c * npad + p] = o >= 0 ? X[c * npad + o] : 0u;
-}
-
-// members above a layer's threshold per POSITION, recovered from the permuted operands: the non-zero rank values of the stored rank words, and
-// "more than they hold" (any value that sends the planner to the bin form) where the suffix behind the last stored word is not empty
-template <bool PACK>
-__global__ void tk_rnode_kernel(const uint32_t *__restrict__ Xp, const uint32_t *__restrict__ sufp, int64_t npad, const HsdSegDesc *__restrict__ tab,
-                                uint32_t *__restrict__ R) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npad) return;
-    const HsdSegDesc d = tab[blockIdx.y];
-    uint32_t cnt = 0;
-    if (d.rank_col0 >= 0 && d.suf_row0 >= 0) {
-        for (int w = 0; w < d.rank_cap; ++w) {
-            const uint32_t v = Xp[(int64_t)(d.rank_col0 + d.rank_low + w) * npad + p];
-            cnt += PACK ? (uint32_t)((v & 0xffffu) != 0u) + (uint32_t)((v >> 16) != 0u) : (uint32_t)(v != 0u);
-        }
-        if (sufp[(int64_t)(d.suf_row0 + d.rank_cap) * npad + p] > 0u) cnt = PACK ? 2u * (uint32_t)d.rank_cap + 2u : (uint32_t)d.rank_cap + 1u;
-    }
-    R[(int64_t)blockIdx.y * npad + p] = cnt;
-}
-
-// bit 31 of a granule's maximum: one of its 16 positions is too wide for the layer's uint8 range (as hsd_pair_prepare marks them)
-__global__ void tk_wide_kernel(const uint32_t *__restrict__ need, int64_t npad, int ngran16, int best_b, int best_r, uint32_t *__restrict__ g16) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngran16) return;
-    bool wide = false;
-    for (int e = 0; e < 16; ++e) wide = wide || (int)need[(int64_t)16 * g + e] > best_b || (int)need[npad + (int64_t)16 * g + e] > best_r;
-    if (wide) g16[g] |= 0x80000000u;
-}
-
-// Fo[f][i] = V[f][i] x the layer's factor (1 / ring size; 1 for the ring-0 value): what the nodes are ordered on
-__global__ void tk_scale_features_kernel(const double *__restrict__ V, const double *__restrict__ inv, int64_t npad, int64_t n, int n_scaled, double *__restrict__ Fo) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int f = blockIdx.y;
-    const double v = V[(int64_t)f * n + i];
-    Fo[(int64_t)f * n + i] = f < n_scaled ? v * inv[(int64_t)f * npad + i] : v;
-}
-
-// per tile of the node order and feature: [min, max] of V over the tile's nodes and their smallest factor (+inf / -inf / +inf for a tile of padding only);
-// 128 threads = one tile, blockIdx.y = feature
-__global__ void tk_tile_interval_kernel(const double *__restrict__ V, const double *__restrict__ inv, int64_t npad, int64_t n, int n_scaled, const int32_t *__restrict__ orig,
-                                        int nt, double *__restrict__ lo, double *__restrict__ hi, double *__restrict__ sc) {
-    __shared__ double part[3][2];
-    const int t = blockIdx.x, f = blockIdx.y;
-    const int32_t o = orig[(int64_t)t * 128 + threadIdx.x];
-    double mn = INFINITY, mx = -INFINITY, s = INFINITY;
-    if (o >= 0) {
-        mn = mx = V[(int64_t)f * n + o];
-        s = f < n_scaled ? inv[(int64_t)f * npad + o] : 1.0;
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        mn = fmin(mn, __shfl_xor(mn, d, 64));
-        mx = fmax(mx, __shfl_xor(mx, d, 64));
-        s = fmin(s, __shfl_xor(s, d, 64));
-    }
-    if ((threadIdx.x & 63u) == 0u) { part[0][threadIdx.x >> 6] = mn; part[1][threadIdx.x >> 6] = mx; part[2][threadIdx.x >> 6] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        lo[(int64_t)f * nt + t] = fmin(part[0][0], part[0][1]);
-        hi[(int64_t)f * nt + t] = fmax(part[1][0], part[1][1]);
-        sc[(int64_t)f * nt + t] = fmin(part[2][0], part[2][1]);
-    }
-}
-
-int tk_prepare(hsd_ctx *ctx) {
-    if (ctx->tk_ready) return HSD_OK;
-    hsd_tk_release(ctx);                               // (whatever an earlier, failed attempt allocated)
-    const bool verbose = hsd_hook(H_TOPK_VERBOSE) != nullptr;
-    if (verbose) (void)hipStreamSynchronize(ctx->stream);          // (whatever hsd_pair_prepare left in flight is not this setup's time)
-    auto t_last = std::chrono::steady_clock::now();
-    auto mark = [&](const char *what) {
-        if (!verbose) return;
-        (void)hipStreamSynchronize(ctx->stream);
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hsd topk] setup: %-34s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-    };
-    const int64_t n = ctx->n, npad = ctx->npad;
-    const bool seg = ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32;
-    const bool pack = ctx->mode == PAIR_SAD_U16;
-    if (npad % 128 != 0) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: operand stride is no whole number of tiles");
-    const int nt = (int)(npad / 128);
-    // bound features V[f][i] with their factors S[f][i] (1 for the raw distance and the ring-0 value; 1 / ring size for a zero-pad layer: the
-    // layer's distance is at least |V_i - V_j| min(S_i, S_j)); the nodes are ordered on V * S
-    int nf = 0, nlay = 0;
-    std::vector<double> V, S;                          // (host copies: only for the host order, HSD_TOPK_ORDER=0)
-    DevTmp dV;                                         // the features on the device, nf rows of n; the zero-pad layers' factors are ctx->d_inv's rows
-    const bool dev_order = hsd_hook_int(H_TOPK_ORDER, 1) != 0;
-    if (!seg) {
-        const int cpl = ctx->l1_cols_per_layer, nl = cpl > 0 ? ctx->dcols_alg / cpl : 0;
-        const int G = std::max(1, std::min(8, hsd_hook_int(H_TOPK_GROUPS, 1)));
-        nlay = nl * G;
-        nf = nlay + (ctx->has_point ? 1 : 0);
-        if (nf < 1) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: nothing to order the nodes by");
-        DevTmp dP;
-        HSD_TMP_ALLOC(ctx, dV, (size_t)nf * n * sizeof(double));
-        HSD_TMP_ALLOC(ctx, dP, (size_t)std::max(nlay, 1) * TK_SLICES * n * sizeof(double));
-        if (nlay > 0)
-            hipLaunchKernelGGL(tk_feature_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(nlay * TK_SLICES)), dim3(256), 0, ctx->stream,
-                               (const double *)ctx->d_X, npad, n, cpl, G, dP.as<double>());
-        hipLaunchKernelGGL(tk_feature_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dP.as<double>(), n, nlay,
-                           ctx->has_point ? (const double *)ctx->d_H : nullptr, dV.as<double>());
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (dP goes)
-    } else {
-        nlay = ctx->n_seg;
-        nf = nlay + (ctx->has_point ? 1 : 0);
-        if (nlay < 1 || !ctx->d_inv) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: no zero-pad layer to order the nodes by");
-        HSD_TMP_ALLOC(ctx, dV, (size_t)nf * n * sizeof(double));
-        if (pack) hipLaunchKernelGGL(tk_feature_seg_kernel<true>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dV.as<double>());
-        else hipLaunchKernelGGL(tk_feature_seg_kernel<false>, dim3((unsigned)((n + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, n, ctx->d_seg_tab, dV.as<double>());
-        if (ctx->has_point)
-            HSD_HIP(ctx, hipMemcpyAsync(dV.as<double>() + (size_t)nlay * n, ctx->d_H, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    if (!dev_order) {
-        V.resize((size_t)nf * n);
-        HSD_HIP(ctx, hipMemcpyAsync(V.data(), dV.p, V.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (seg) {
-            S.assign((size_t)nf * n, 1.0);
-            for (int s2 = 0; s2 < nlay; ++s2)
-                HSD_HIP(ctx, hipMemcpyAsync(S.data() + (size_t)s2 * n, ctx->d_inv + (size_t)s2 * npad, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        }
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    mark("features");
-    int rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, (size_t)nf * nt))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, (size_t)nf * nt))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_scale, (size_t)nf * nt))) return rc;
-    if (dev_order) {
-        // the order on the device (csrc/tkorder.hip), on V x factor (zero-pad layers: the ring's MEAN value); then every tile's feature intervals
-        DevTmp dFo;
-        const double *Fo = dV.as<double>();
-        if (seg) {
-            HSD_TMP_ALLOC(ctx, dFo, (size_t)nf * n * sizeof(double));
-            hipLaunchKernelGGL(tk_scale_features_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, dV.as<double>(), (const double *)ctx->d_inv,
-                               npad, n, nlay, dFo.as<double>());
-            Fo = dFo.as<double>();
-        }
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_orig, 0xff, (size_t)npad * sizeof(int32_t), ctx->stream));          // padding positions: -1
-        if ((rc = hsd_tk_order_device(ctx, Fo, n, nf, ctx->d_tk_orig))) return rc;
-        mark("k-d order (device)");
-        hipLaunchKernelGGL(tk_tile_interval_kernel, dim3((unsigned)nt, (unsigned)nf), dim3(128), 0, ctx->stream, dV.as<double>(), seg ? (const double *)ctx->d_inv : nullptr,
-                           npad, n, seg ? nlay : 0, (const int32_t *)ctx->d_tk_orig, nt, ctx->d_tk_lo, ctx->d_tk_hi, ctx->d_tk_scale);
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (dFo goes)
-    } else {
-        std::vector<int32_t> idx;
-        {
-            std::vector<double> Fo = V;
-            if (seg) for (size_t q = 0; q < Fo.size(); ++q) Fo[q] *= S[q];
-            kd_order_host(Fo, n, nf, idx);
-        }
-        mark("k-d order (host)");
-        std::vector<int32_t> orig((size_t)npad, -1);
-        std::copy(idx.begin(), idx.end(), orig.begin());
-        std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY), fsc((size_t)nf * nt, INFINITY);
-        for (int64_t p = 0; p < n; ++p)
-            for (int f = 0; f < nf; ++f) {
-                const size_t src = (size_t)f * n + idx[(size_t)p], dst = (size_t)f * nt + p / 128;
-                flo[dst] = std::min(flo[dst], V[src]); fhi[dst] = std::max(fhi[dst], V[src]);
-                fsc[dst] = std::min(fsc[dst], seg ? S[src] : 1.0);
-            }
-        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_lo, flo.data(), flo.size() * sizeof(double), hipMemcpyHostToDevice));
-        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_hi, fhi.data(), fhi.size() * sizeof(double), hipMemcpyHostToDevice));
-        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_scale, fsc.data(), fsc.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    const int band_w = std::max(1, std::min(4, hsd_hook_int(H_TOPK_BAND, 1)));      // the first launch: every tile with itself and its band_w successors
-    std::vector<int2> band;
-    for (int t = 0; t < nt; ++t)
-        for (int d = 0; d <= band_w && t + d < nt; ++d) band.push_back(make_int2(t, t + d));
-    ctx->tk_band_w = band_w;
-    mark("tile intervals + first-launch list");
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npad))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
-    ctx->tk_list_cap = (int)std::min<int64_t>((int64_t)nt * (nt + 1) / 2, 0x7fffffff);
-    HSD_HIP(ctx, hipMalloc(&ctx->d_tk_list, (size_t)ctx->tk_list_cap * sizeof(int2)));
-    HSD_HIP(ctx, hipMalloc(&ctx->d_tk_band, band.size() * sizeof(int2)));
-    ctx->tk_band_n = (int)band.size();
-    HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
-    const dim3 pgrid((unsigned)((npad + 255) / 256));
-    if (ctx->has_point)
-        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, ctx->d_tk_H);
-    if (!seg) {
-        const int cols = std::max(ctx->dcols, 16);
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, (size_t)cols * npad))) return rc;
-        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, ctx->d_tk_orig, ctx->d_tk_X);
-    } else {
-        // the zero-pad kinds' operands: packed words, 1 / ring size per layer, suffix sums -- and, recovered from them, what the tile planner reads:
-        // members above each layer's threshold per position -> maxima per 16-position granule (+ the "too wide for the uint8 range" flags) -> per tile
-        const int cols = std::max(ctx->dcols, 32), ngran16 = (int)(npad / 16);
-        const int64_t sufr = (int64_t)ctx->suf_rows + 1;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_U, (size_t)cols * npad))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_inv, (size_t)nlay * npad))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_suf, (size_t)sufr * npad))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_rmax16, (size_t)nlay * ngran16))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmaxs, (size_t)nlay * nt))) return rc;
-        hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, ctx->d_tk_orig, ctx->d_tk_U);
-        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, (const double *)ctx->d_inv, npad, ctx->d_tk_orig, ctx->d_tk_inv);
-        if (ctx->d_suf) hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)sufr), dim3(256), 0, ctx->stream, ctx->d_suf, npad, ctx->d_tk_orig, ctx->d_tk_suf);
-        else HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_suf, 0, (size_t)sufr * npad * sizeof(uint32_t), ctx->stream));
-        DevTmp dR, dneed;
-        HSD_TMP_ALLOC(ctx, dR, (size_t)nlay * npad * sizeof(uint32_t));
-        HSD_TMP_ALLOC(ctx, dneed, (size_t)2 * npad * sizeof(uint32_t));
-        if (pack) hipLaunchKernelGGL(tk_rnode_kernel<true>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npad, ctx->d_seg_tab, dR.as<uint32_t>());
-        else hipLaunchKernelGGL(tk_rnode_kernel<false>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npad, ctx->d_seg_tab, dR.as<uint32_t>());
-        hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, dR.as<uint32_t>(), npad, ngran16, ctx->d_tk_rmax16);
-        for (int s2 = 0; s2 < nlay && pack; ++s2) {
-            const HsdSegDesc &d = ctx->seg_tab[s2];
-            if (d.r8_col0 < 0) continue;
-            HSD_HIP(ctx, hipMemsetAsync(dneed.p, 0, (size_t)2 * npad * sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(u8_need_kernel, dim3(pgrid.x), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_tk_U, npad, npad, d, dneed.as<uint32_t>());
-            hipLaunchKernelGGL(tk_wide_kernel, dim3((unsigned)((ngran16 + 255) / 256)), dim3(256), 0, ctx->stream, dneed.as<uint32_t>(), npad, ngran16, d.r8_k16 - d.r8_r16, d.r8_r16,
-                               ctx->d_tk_rmax16 + (size_t)s2 * ngran16);
-        }
-        std::vector<int32_t> gl((size_t)ngran16);
-        for (int g = 0; g < ngran16; ++g) gl[(size_t)g] = g;
-        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_tk_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(list_tile_max_kernel, dim3((unsigned)(((int64_t)nt * nlay + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_gl, nt, ctx->d_tk_rmax16, ngran16, nlay,
-                           ctx->d_tk_tmaxs);
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (gl, the temporaries)
-    }
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    mark("allocations + permuted operands");
-    ctx->tk_nf = nf; ctx->tk_nt = nt;
-    ctx->tk_ready = true;
-    return HSD_OK;
-}
-
-// *done = false: not applicable (or a list overflowed): the caller runs the unpruned sweep
-int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *done) {
-    *done = false;
-    const int64_t n = ctx->n, npad = ctx->npad;
-    const bool seg = ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32;
-    PairArgs a{};
-    a.npad = npad;
-    a.dcols = ctx->dcols;
-    a.n_seg = seg ? ctx->n_seg : 0;
-    a.list_cap = ctx->list_cap;
-    a.dcols_valid = ctx->dcols_alg;
-    { const char *e = hsd_hook(H_TOPK_DEBUG); a.dbg = e ? atoi(e) : 0; }
-    a.rbase = 0;
-    a.i_begin = 0; a.i_end = npad; a.j_begin = 0; a.j_end = npad;
-    a.sym = 1; a.mirror = 1;
-    {
-        // the persistent kernel must take the region (its LDS budget: at most three per-node vectors)
-        if (a.n_seg + (ctx->has_point ? 1 : 0) > 3) return HSD_OK;
-        PairArgs probe = a;
-        probe.tau = reinterpret_cast<const double *>(ctx);          // (any non-null value: the k-nearest kernels have no output alignment to check)
-        if (!stream_waves(ctx, probe)) return HSD_OK;
-    }
-    int rc = tk_prepare(ctx);
-    if (rc) return rc;
-    if (seg) {
-        a.X = a.Y = ctx->d_tk_U;
-        a.inv = ctx->d_tk_inv;
-        a.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
-        a.rmax = ctx->d_rmax;
-        a.ngran = ctx->ngran;
-        a.suf = ctx->d_tk_suf;
-        a.gl_ov = ctx->d_tk_gl; a.tmax_ov = ctx->d_tk_tmaxs; a.ntl_ov = ctx->tk_nt;
-    } else {
-        a.X = a.Y = ctx->d_tk_X;
-    }
-    a.point = ctx->has_point ? ctx->d_tk_H : nullptr;
-    a.orig_of = ctx->d_tk_orig;
-    const int64_t rows = npad;
-    const int64_t cap = std::max<int64_t>(2048, 512 + 8 * (int64_t)k);
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t oTau = carve((size_t)rows * sizeof(double)), oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
-    const size_t oVal = carve((size_t)rows * cap * sizeof(double)), oOi = carve((size_t)rows * k * sizeof(int)), oOv = carve((size_t)rows * k * sizeof(double));
-    const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64), oFi = carve((size_t)n * k * sizeof(int)), oFv = carve((size_t)n * k * sizeof(double));
-    const int64_t M = std::min<int64_t>(n, 1024), ldS = (M + 127) / 128 * 128;
-    const size_t oS = carve((size_t)n * ldS * sizeof(double)), oTn = carve((size_t)n * sizeof(double));
-    if (ctx->scratch_bytes < off) {
-        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-        ctx->d_scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        HSD_HIP(ctx, hipMalloc(&ctx->d_scratch, off));
-        ctx->scratch_bytes = off;
-    }
-    char *base = static_cast<char *>(ctx->d_scratch);
-    double *d_tau = reinterpret_cast<double *>(base + oTau), *d_val = reinterpret_cast<double *>(base + oVal), *d_oval = reinterpret_cast<double *>(base + oOv);
-    double *d_fval = reinterpret_cast<double *>(base + oFv);
-    int *d_cnt = reinterpret_cast<int *>(base + oCnt), *d_idx = reinterpret_cast<int *>(base + oIdx), *d_oidx = reinterpret_cast<int *>(base + oOi);
-    int *d_fidx = reinterpret_cast<int *>(base + oFi);
-    HSD_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)rows * sizeof(int), ctx->stream));
-    HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
-    // First thresholds, part one: the k-th smallest of 1 024 columns spread evenly over the NATURAL node order (the unpruned sweep's own first
-    // thresholds, computed on the untouched operands).  A row unlike everything near it in the k-d order -- a hub, whose distances to the
-    // thousands of leaves crowd just above its k-th -- would otherwise start from a threshold that admits most of the graph (zero-pad distance,
-    // BA N = 100k: lists of 38 000 entries).  Part two, the tiles next to a row's own, only tightens it.  The raw fp64 distance starts from
-    // +inf: its lists stay short without the sample (longest 709 of 2 048 at BA N = 100k, 27 000 soak calls), which would cost it 4.4 ms
-    // of arithmetic + 0.8 GB of sample matrix per call (66.7 -> 74.4 ms, measured).
-    if (!seg) hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_tau, rows, (double)INFINITY);
-    else {
-        double *d_S = reinterpret_cast<double *>(base + oS), *d_tauN = reinterpret_cast<double *>(base + oTn);
-        PairArgs nat{};
-        nat.X = ctx->d_X; nat.Y = ctx->d_X;
-        nat.inv = ctx->d_inv;
-        nat.point = ctx->has_point ? ctx->d_H : nullptr;
-        nat.npad = npad; nat.dcols = ctx->dcols; nat.n_seg = ctx->n_seg;
-        nat.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
-        nat.rmax = ctx->d_rmax; nat.ngran = ctx->ngran; nat.list_cap = ctx->list_cap;
-        nat.dcols_valid = ctx->dcols_alg;
-        nat.rbase = 0; nat.i_begin = 0; nat.i_end = n;
-        const int n_sub = (int)((M + 127) / 128);
-        const int64_t n_tiles_total = (n + 127) / 128;
-        for (int t = 0; t < n_sub; ++t) {
-            const int64_t tile = n_sub >= n_tiles_total ? t : (int64_t)t * n_tiles_total / n_sub;
-            PairArgs sub = nat;
-            sub.j_begin = tile * 128;
-            sub.j_end = std::min<int64_t>(n, sub.j_begin + 128);
-            sub.out = d_S + (int64_t)t * 128 - sub.j_begin;
-            sub.ld = ldS;
-            if ((rc = launch_region(ctx, sub, tile_edge(ctx), ctx->stream))) return rc;
-            if (sub.j_end - sub.j_begin < 128)
-                hipLaunchKernelGGL(fill_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_S, ldS, n, (int)(t * 128 + (sub.j_end - sub.j_begin)),
-                                   (int)((t + 1) * 128), (double)INFINITY);
-        }
-        hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, n_sub * 128, (int64_t)0, n, k, 0.0, d_tauN);
-        hipLaunchKernelGGL(tk_permute_tau_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig, rows, d_tauN, d_tau);
-    }
-    PairArgs b = a;
-    b.tau = d_tau; b.cand_cnt = d_cnt; b.cand_idx = d_idx; b.cand_val = d_val; b.cand_cap = (int)cap;
-    b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16);
-    const int BT = tile_edge(ctx);
-    const size_t cmp_lds = (size_t)4 * k * 12;
-    // launch 0: every row against the tiles next to its own in the order, under thresholds of +inf; then the first real thresholds
-    b.explicit_tiles = reinterpret_cast<const int2 *>(ctx->d_tk_band); b.n_explicit = ctx->tk_band_n;
-    if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
-    hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
-    // the rest of the pair space in anti-diagonal phases, each filtered against the thresholds of the moment (tightened after phases 1, 2, 4)
-    b.explicit_tiles = nullptr; b.n_explicit = 0;
-    b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_scale = seg ? ctx->d_tk_scale : nullptr; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = ctx->tk_band_w;
-    // (measured at BA N = 100k: 2 phases overflow the lists -- the band thresholds meet half the columns at once --, 3 / 4 / 5 / 6 / 8 / 12 / 16 take
-    //  66.3 / 65.7 / 65.6 / 66.8 / 68.8 / 72.1 / 74.5 ms with longest lists of 847 / 690 / 296 / 360 / 709 entries; twice the nodes, twice the appends per phase)
-    int n_phases = ctx->tk_nt <= 1200 ? 5 : 8;
-    if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
-    for (int ph = 0; ph < n_phases; ++ph) {
-        b.phase = ph; b.phase_w = 1; b.n_phases = n_phases;
-        if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
-        if (ph + 1 < n_phases && ((ph + 1) & ph) == 0)
-            hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
-    }
-    // select (the rows of real nodes are the first n positions), back to node order, out
-    int flag[4] = {0, 0, 0, 0};
-    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap, (int64_t)0, n, k, d_oidx, d_oval,
-                       ctx->d_flag);
-    hipLaunchKernelGGL(tk_unpermute_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig, n, k, d_oidx, d_oval, d_fidx, d_fval);
-    HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    HSD_HIP(ctx, hipGetLastError());
-    if (hsd_hook(H_TOPK_VERBOSE)) {
-        std::vector<int> hc((size_t)n);
-        (void)hipMemcpy(hc.data(), d_cnt, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
-        int64_t mx = 0;
-        for (int v : hc) mx = std::max<int64_t>(mx, v);
-        fprintf(stderr, "[hsd topk] pruned sweep: capacity %lld, longest list %lld, overflow %d\n", (long long)cap, (long long)mx, flag[0] & 1);
-    }
-    if (flag[0] & 1) return HSD_OK;                 // a list overflowed (or came up short): the unpruned sweep takes the call
-    HSD_HIP(ctx, hipMemcpyAsync(idx_out, d_fidx, (size_t)n * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipMemcpyAsync(dist_out, d_fval, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *done = true;
-    return HSD_OK;
-}
-
-}  // namespace
-
-extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out) try {
-    HSD_CHECK_CTX(ctx);
-    if (ctx->mode == PAIR_NONE) return hsd_fail(ctx, HSD_ERR_NO_SIGNATURE, "hsd_pair_prepare has not been called");
-    if (ctx->mode == PAIR_KL)
-        return hsd_fail(ctx, HSD_ERR_UNSUPPORTED, "top-k is offered for the symmetric distances (wasserstein, symmetric_kl)");
-    const int64_t n = ctx->n;
-    if (r0 < 0 || r1 > n || r0 > r1) return hsd_fail(ctx, HSD_ERR_INVALID, "row range out of bounds");
-    if (k < 1 || k > n - 1 || k > 1024) return hsd_fail(ctx, HSD_ERR_INVALID, "k=%d must be in [1, min(n-1, 1024)]", k);
-    if (r0 == r1) return HSD_OK;
-    if (!idx_out || !dist_out) return hsd_fail(ctx, HSD_ERR_INVALID, "null output");
-    const int64_t rows = r1 - r0;
-    const bool wass = ctx->mode == PAIR_L1_F64 || ctx->mode == PAIR_SAD_U32 || ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_ZP_F64;
-    {
-        // raw fp64 W1 over the whole graph: the pruned sweep on node-permuted operands (above) where it applies
-        const int pr = hsd_hook_int(H_TOPK_PRUNE, -1);
-        // (the zero-pad kinds from ~50k nodes (384 tiles) on, or on request: where a FIRST call -- one-time setup included -- is ahead of the unpruned
-        //  call.  BA N = 40k: 5.05 ms unpruned against 5.2-5.3 for a first call, 4.1 for every later one; N = 60k: 9.1-9.6 against 7.5-7.8 / 6.1;
-        //  N = 80k: 13.8-14.6 against 10.8-11.5 / 8.8; N = 100k: 20.0-20.9 against 15.4 / 12.0; N = 200k: 73 against 33.4 for a later call.  With the node order from host threads (HSD_TOPK_ORDER=0) the first calls were
-        //  12.4-13.0 and 20.9-21.5 ms and the default began at 100k nodes.)
-        const bool l1 = ctx->mode == PAIR_L1_F64 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0;
-        const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && (pr == 1 || (pr != 0 && ctx->npad / 128 >= 384));
-        if ((l1 || zp) && r0 == 0 && r1 == n && k <= 128 && !hsd_hook(H_TOPK_GEOM)) {
-            bool done = false;
-            const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);
-            if (rcp != HSD_OK || done) return rcp;
-        }
-    }
-
-    PairArgs a{};
-    a.X = ctx->d_X;
-    a.Y = wass ? ctx->d_X : ctx->d_Y;
-    a.H = wass ? nullptr : ctx->d_H;
-    a.inv = ctx->d_inv;
-    a.point = ctx->has_point ? (wass ? ctx->d_H : ctx->d_H + ctx->npad) : nullptr;
-    a.point_c = ctx->kl_point_c;
-    a.npad = ctx->npad;
-    a.dcols = ctx->dcols;
-    a.n_seg = ctx->n_seg;
-    a.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
-    a.rmax = ctx->d_rmax;
-    a.ngran = ctx->ngran;
-    a.list_cap = ctx->list_cap;
-    a.work = nullptr;
-    a.hmode = ctx->mode == PAIR_SKL ? 1 : 0;
-    { const char *e = hsd_hook(H_TOPK_DEBUG); a.dbg = e ? atoi(e) : 0; }     // measurement: 1 = sweep without its candidate epilogue
-    a.dcols_valid = (ctx->mode == PAIR_SKL) ? ctx->dcols : ctx->dcols_alg;
-    a.rbase = r0;
-    a.i_begin = r0; a.i_end = r1;
-
-    const double slack = ctx->mode == PAIR_SKL ? 1e-11 : 0.0;      // W1 is evaluated identically in both orientations of a pair
-    int64_t M = std::min<int64_t>(n, std::max<int64_t>(1024, 4 * (int64_t)k));
-    // A large sweep runs in phases (anti-diagonal samples of the tile groups, tile_order): after each one every row keeps
-    // its k best and tightens its threshold, so that the candidates appended per row fall from ~ k n / M to
-    // ~ k n / (M P) + k (1 + 1/2 + .. + 1/(P-1)).  HSD_TOPK_PHASES forces a count (tests).
-    int n_phases = 1;
-    // HSD_TOPK_GEOM=1 (opt-in, measured): the launches GEOMETRICALLY instead of in equal phases: 1/32, 1/32, 1/16, 1/8, 1/4, 1/2 of the tile groups
-    // (residues [0,1), [1,2), [2,4), [4,8), [8,16), [16,32) of the anti-diagonal index mod 32).  What phases save are appends
-    // (~0.09 ms per million at BA N = 100k), and appends are (columns of the launch) x k / (columns the thresholds have seen): the
-    // loose first thresholds -- from a 1 % sample -- then meet 3 % of the columns instead of 12.5 % (61 instead of 244 appends per
-    // row), and every later launch doubles what the thresholds know.  Lists are compacted (0.42 ms) where that saves more in the
-    // next launch than it costs -- after the first and the fourth -- and after the fifth: rows whose k-th distance is shared by thousands of
-    // columns (leaves of a scale-free graph with identical rings: the integer distances tie exactly) append every one of them, and the
-    // last launch alone covers half the columns (without it 4 of 100 000 rows overflowed 2 048 entries and the call was repeated).
-    // Zero-pad distance: 20.1 -> 19.4-19.9 ms at BA N = 100k, 71.7 -> 66.3 ms at N = 200k.  NOT the default: rows whose distances to
-    // most columns lie in a narrow band just above their k-th (hubs against the leaves) keep a threshold inside that band after a
-    // first launch that shows them only 3 % of the columns, and append thousands in the launches that follow -- raw fp64 W1 at BA
-    // N = 100k: 1 956 rows overflow 2 048 entries (longest list 7 663) and the call is repeated at twice the price (equal phases:
-    // longest list 441).
-    bool geometric = false;
-    {
-        const int64_t t128 = (rows + 127) / 128, tiles = t128 * ((n + 127) / 128);
-        const int cus = std::max(1, ctx->prop.multiProcessorCount);
-        while (n_phases < 8 && tiles / (2 * n_phases) >= 64 * (int64_t)cus) n_phases *= 2;
-        if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
-        else if (const char *eg = hsd_hook(H_TOPK_GEOM)) geometric = atoi(eg) != 0;
-    }
-    struct Launch { int lo, w, mod; bool compact_after; };
-    std::vector<Launch> sched;
-    if (geometric) {
-        sched = {{0, 1, 32, true}, {1, 1, 32, false}, {2, 2, 32, false}, {4, 4, 32, true}, {8, 8, 32, true}, {16, 16, 32, false}};
-        n_phases = 32;                                // (the list capacity below is sized by the first launch's share)
-    } else if (n_phases == 8 && !hsd_hook(H_TOPK_PHASES)) {
-        // eight equal phases with the FIRST one in two halves and a compaction in between: the sampled thresholds are the loosest
-        // the sweep ever uses (a 2 % quantile), and half a phase under them appends 122 instead of 244 entries per row before the
-        // first tightening (-10^7 appends at BA N = 100k against 0.42 ms for the extra compaction: 19.5 -> 19.25 ms; N = 200k: 72 -> 66 ms).
-        // Longest list 776 (zero-pad) / 940 (raw fp64) of 2 177 entries, plain equal phases 416 / 441: rows whose distances crowd just
-        // above their k-th tighten less after half a phase.  Compaction otherwise after phases 1, 2, 4 as below.
-        sched = {{0, 1, 16, true}, {1, 1, 16, true}, {2, 2, 16, true}, {4, 2, 16, false}, {6, 2, 16, true},
-                 {8, 2, 16, false}, {10, 2, 16, false}, {12, 2, 16, false}, {14, 2, 16, false}};
-        // (n_phases stays 8: the list capacity below is the one equal phases were validated with)
-    } else {
-        // equal phases; the thresholds tighten fastest early on: compact after phases 1, 2, 4, ... (phases 5-8 of 8 together append ~k entries)
-        for (int ph = 0; ph < n_phases; ++ph) sched.push_back({ph, 1, n_phases, ph + 1 < n_phases && ((ph + 1) & ph) == 0});
-    }
-    // list capacity: the expected candidates of the first phase (k / M of a row's n / P columns) with room for rows of many
-    // equal distances (the integer zero-pad distances tie by the hundred); an overflow anywhere costs a whole retry
-    int64_t cap = std::min<int64_t>(n, n_phases > 1 ? std::max<int64_t>(2048, 8 * (int64_t)k * n / (M * n_phases) + 8 * k + 64)
-                                                    : std::max<int64_t>(256, 4 * (int64_t)k * n / M + 64));
-    if (const char *ec = hsd_hook(H_TOPK_CAP)) cap = std::min<int64_t>(n, std::max<int64_t>(k + 1, atoll(ec)));   // test hook
-    int rc = HSD_OK;
-    for (int attempt = 0; attempt < 3 && rc == HSD_OK; ++attempt) {
-        if (attempt == 1) { M = std::min<int64_t>(n, 4 * M); cap = std::min<int64_t>(n, 8 * cap); }
-        if (attempt == 2) { M = std::min<int64_t>(n, 16384); cap = n; }
-        M = std::min<int64_t>(M, 16384);
-        const int64_t ldS = (M + 127) / 128 * 128;
-        // scratch: one grow-only arena per context (allocating gigabytes per call would dominate)
-        size_t off = 0;
-        auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-        const size_t oS = carve((size_t)rows * ldS * sizeof(double)), oTau = carve((size_t)rows * sizeof(double));
-        const size_t oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
-        const size_t oVal = carve((size_t)rows * cap * sizeof(double)), oOi = carve((size_t)rows * k * sizeof(int));
-        const size_t oOv = carve((size_t)rows * k * sizeof(double));
-        const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64);
-        if (ctx->scratch_bytes < off) {
-            HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-            ctx->d_scratch = nullptr;
-            ctx->scratch_bytes = 0;
-            HSD_HIP(ctx, hipMalloc(&ctx->d_scratch, off));
-            ctx->scratch_bytes = off;
-        }
-        char *base = static_cast<char *>(ctx->d_scratch);
-        double *d_S = reinterpret_cast<double *>(base + oS), *d_tau = reinterpret_cast<double *>(base + oTau);
-        double *d_val = reinterpret_cast<double *>(base + oVal), *d_oval = reinterpret_cast<double *>(base + oOv);
-        int *d_cnt = reinterpret_cast<int *>(base + oCnt), *d_idx = reinterpret_cast<int *>(base + oIdx);
-        int *d_oidx = reinterpret_cast<int *>(base + oOi);
-        hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)rows * sizeof(int), ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream);
-        // 1. threshold from M columns taken as 128-node tiles spread evenly over the node order (the
-        //    first M nodes would be a biased sample: e.g. the oldest = highest-degree nodes of a
-        //    preferential-attachment graph); column t*128 + u of S is node tile_start(t) + u
-        const int n_sub = (int)((M + 127) / 128);
-        const int64_t n_tiles_total = (n + 127) / 128;
-        for (int t = 0; t < n_sub && rc == HSD_OK && e == hipSuccess; ++t) {
-            const int64_t tile = n_sub >= n_tiles_total ? t : (int64_t)t * n_tiles_total / n_sub;
-            PairArgs sub = a;
-            sub.j_begin = tile * 128;
-            sub.j_end = std::min<int64_t>(n, sub.j_begin + 128);
-            sub.out = d_S + (int64_t)t * 128 - sub.j_begin;      // out[(i - r0) * ld + j] lands in column t*128 + (j - j_begin)
-            sub.ld = ldS; sub.sym = 0; sub.mirror = 0; sub.swap = 0; sub.tau = nullptr;
-            rc = launch_region(ctx, sub, tile_edge(ctx), ctx->stream);
-            if (rc == HSD_OK && sub.j_end - sub.j_begin < 128)   // last, partial tile: pad with +inf
-                hipLaunchKernelGGL(fill_columns_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_S, ldS, rows,
-                                   (int)(t * 128 + (sub.j_end - sub.j_begin)), (int)((t + 1) * 128), (double)INFINITY);
-        }
-        if (rc == HSD_OK && e == hipSuccess) {
-            const int Ms = n_sub * 128;
-            hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, Ms, r0, rows, k, slack, d_tau - r0);
-        }
-        // 2. sweep: square on the diagonal (both rows of a pair are ours) + the blocks left and right of it
-        for (size_t li = 0; li < sched.size() && rc == HSD_OK && e == hipSuccess; ++li) {
-            const Launch &L = sched[li];
-            PairArgs b = a;
-            b.out = nullptr; b.ld = 0;
-            b.tau = d_tau - r0; b.cand_cnt = d_cnt - r0; b.cand_idx = d_idx - r0 * cap; b.cand_val = d_val - r0 * cap; b.cand_cap = (int)cap;
-            b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16) - r0;
-            b.phase = L.lo; b.phase_w = L.w; b.n_phases = L.mod;
-            b.j_begin = r0; b.j_end = r1; b.sym = 1; b.mirror = 1; b.swap = 0;
-            const int BT = tile_edge(ctx);
-            rc = launch_region(ctx, b, BT, ctx->stream);
-            b.sym = 0; b.mirror = 0;
-            if (rc == HSD_OK && r0 > 0) { b.j_begin = 0; b.j_end = r0; rc = launch_region(ctx, b, BT, ctx->stream); }
-            if (rc == HSD_OK && r1 < n) { b.j_begin = r1; b.j_end = n; rc = launch_region(ctx, b, BT, ctx->stream); }
-            if (rc == HSD_OK && L.compact_after)
-                hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), (size_t)4 * k * 12, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, slack, d_tau);
-        }
-        // 3. select
-        int flag[4] = {0, 0, 0, 0};
-        if (rc == HSD_OK && e == hipSuccess) {
-            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap,
-                               (int64_t)0, rows, k, d_oidx, d_oval, ctx->d_flag);
-            e = hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e == hipSuccess) e = hipGetLastError();
-        }
-        if (hsd_hook(H_TOPK_VERBOSE) && rc == HSD_OK && e == hipSuccess) {
-            std::vector<int> hc((size_t)rows);
-            (void)hipMemcpy(hc.data(), d_cnt, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost);
-            int64_t mx = 0, over = 0;
-            for (int v : hc) { mx = std::max<int64_t>(mx, v); over += v > cap; }
-            fprintf(stderr, "[hsd topk] attempt %d: M %lld, phases %d, capacity %lld, longest list %lld, rows over capacity %lld\n", attempt,
-                    (long long)M, n_phases, (long long)cap, (long long)mx, (long long)over);
-        }
-        const bool again = rc == HSD_OK && e == hipSuccess && (flag[0] & 1) && attempt < 2;
-        if (rc == HSD_OK && e == hipSuccess && !(flag[0] & 1)) {
-            e = hipMemcpyAsync(idx_out, d_oidx, (size_t)rows * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(dist_out, d_oval, (size_t)rows * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        }
-        (void)hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "hsd_pair_topk: %s", hipGetErrorString(e));
-        if (rc != HSD_OK) return rc;
-        if (!again) {
-            if (flag[0] & 1) return hsd_fail(ctx, HSD_ERR_TOO_LARGE, "hsd_pair_topk: candidate lists overflowed even at capacity n");
-            return HSD_OK;
-        }
-    }
-    return rc;
-} HSD_ABI_GUARD(ctx)

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .engine import HsdError
+
 
 def rows_per_rank(n, world):
     rpr = (n + world - 1) // world
@@ -32,7 +34,11 @@ def init_comm(engine, dist, rank, world, host_fallback=False):
 
     host_fallback=True: if ncclCommInitRank fails on ANY rank (the ranks agree through `dist`), every rank commits the same row
     partition without a communicator instead of raising, and `engine.exchange` says "host": allgather_signature then moves the counts
-    through host memory (gloo).  The distance kernels do not care how the counts arrived."""
+    through host memory (gloo).  The distance kernels do not care how the counts arrived.
+    What the fallback covers: SYMMETRIC failures -- a node without working RCCL, where ncclCommInitRank returns an error on the ranks that call
+    it.  It does not cover one hung or dead rank: ncclCommInitRank is collective, so its peers block in it (RCCL's own timeout ends that), and
+    no agreement through `dist` can be reached with a rank that is gone.  Not thread-safe: the dry-run commit below toggles a process-wide
+    environment hook for the duration of one call (one context per process is the deployment this serves)."""
     import os
     import torch
     idt = torch.zeros(128, dtype=torch.uint8)
@@ -42,7 +48,7 @@ def init_comm(engine, dist, rank, world, host_fallback=False):
     err = None
     try:
         engine.comm_init(world, rank, bytes(idt.numpy().tobytes()))
-    except Exception as e:      # noqa: BLE001  (HsdError: ncclCommInitRank failed)
+    except HsdError as e:       # ncclCommInitRank failed on this rank (anything else -- a TypeError, a bad argument -- is a bug and propagates)
         if not host_fallback:
             raise
         err = e

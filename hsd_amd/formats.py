@@ -137,14 +137,3 @@ def read_label(path) -> dict:
     except Exception:                       # the reference's `finally: return label_dict`: partial result, no exception
         pass
     return labels
-    with open(path, encoding="utf-8") as fin:
-        for raw in fin:
-            record = raw.strip()
-            if record == "":
-                break
-            try:
-                node, label = record.split(" ")
-                labels[node] = int(label)
-            except ValueError:
-                break                   # the reference's `finally: return label_dict`: partial result, no exception
-    return labels

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define HSD_ABI_VERSION 1
+/* 2: hsd_pair_shard, status codes -10 / -11 (round 4); hsd_pair_topk takes the pruned sweep for row blocks (round 5: same signature) */
+#define HSD_ABI_VERSION 2
 
 /* status codes */
 #define HSD_OK                    0

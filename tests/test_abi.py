@@ -38,7 +38,7 @@ def test_header_symbols_exported():
 def test_loader_sets_prototypes_and_version():
     from hsd_amd import _lib
     lib = _lib.load()
-    assert lib.hsd_abi_version() == 1
+    assert lib.hsd_abi_version() == 2 == _lib.ABI_VERSION
     assert lib.hsd_strerror(-5) == b"Distribution can't be empty."
     assert lib.hsd_strerror(-8) == b"The sum of probability distribution must be 1.0."
     assert lib.hsd_strerror(_lib.ERR_NOMEM) == b"out of host memory" and b"exception" in lib.hsd_strerror(_lib.ERR_INTERNAL)

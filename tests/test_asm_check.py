@@ -67,3 +67,71 @@ def test_check_reports_missing_objdump(monkeypatch, tmp_path):
     monkeypatch.setenv("ROCM_PATH", str(tmp_path))
     monkeypatch.setenv("PATH", str(tmp_path))
     assert m.find_objdump() is None
+
+
+# ---- hsd_amd/csrc/check_resources.py: the register / scratch contract of the all-pairs kernels ----
+def _res():
+    spec = importlib.util.spec_from_file_location("check_resources", os.path.join(REPO, "hsd_amd", "csrc", "check_resources.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _notes(kernels):
+    """llvm-readelf --notes text of a code object with these kernels (name, fields)"""
+    out = ["Displaying notes found in: .note", "    AMDGPU Metadata:", "        ---", "amdhsa.kernels:"]
+    for name, f in kernels:
+        out += ["  - .agpr_count:     %d" % f.get("agpr_count", 0), "    .args:", "      - .offset:         0", "        .size:           8",
+                "        .value_kind:     by_value", "    .group_segment_fixed_size: %d" % f.get("group_segment_fixed_size", 0),
+                "    .max_flat_workgroup_size: 256", "    .name:           " + name,
+                "    .private_segment_fixed_size: %d" % f.get("private_segment_fixed_size", 0), "    .sgpr_count:     %d" % f.get("sgpr_count", 100),
+                "    .sgpr_spill_count: %d" % f.get("sgpr_spill_count", 0), "    .symbol:         " + name + ".kd",
+                "    .vgpr_count:     %d" % f.get("vgpr_count", 0), "    .vgpr_spill_count: %d" % f.get("vgpr_spill_count", 0)]
+    out += ["amdhsa.target:   amdgcn-amd-amdhsa--gfx950", "amdhsa.version:", "  - 1", "  - 2"]
+    return "\n".join(out) + "\n"
+
+
+HEADLINE = "_ZN8hsd_pair18pair_stream_kernelILi4ELi4ELb0EEEvNS_8PairArgsE"
+SWEEP = "_ZN8hsd_pair18pair_stream_kernelILi0ELi4ELb1EEEvNS_8PairArgsE"
+ONE_TILE = "_ZN8hsd_pair11pair_kernelILi4ELb0ELi8EEEvNS_8PairArgsE"
+SMALL_TILE = "_ZN8hsd_pair11pair_kernelILi0ELb1ELi4EEEvNS_8PairArgsE"
+
+
+def test_resource_contract_as_built_passes_and_parses_every_field():
+    m = _res()
+    ks = m.parse_kernels(_notes([(HEADLINE, dict(vgpr_count=255, sgpr_count=106, sgpr_spill_count=146)),
+                                 (ONE_TILE, dict(vgpr_count=256, vgpr_spill_count=17, private_segment_fixed_size=72)),
+                                 ("_ZN12_GLOBAL__N_114u8_need_kernelEPKjll10HsdSegDescPj", dict(vgpr_count=12))]))
+    assert [k["name"] for k in ks] == [HEADLINE, ONE_TILE, "_ZN12_GLOBAL__N_114u8_need_kernelEPKjll10HsdSegDescPj"]
+    assert ks[0]["vgpr_count"] == 255 and ks[0]["sgpr_spill_count"] == 146 and ks[1]["private_segment_fixed_size"] == 72
+    assert all(m.check_kernel(k) == [] for k in ks)          # scalar spills into vector lanes are by design; the unaligned one-tile kernel may hold 72 B
+
+
+def test_resource_contract_flags_the_cliffs():
+    m = _res()
+    def bad(name, **f):
+        (k,) = m.parse_kernels(_notes([(name, f)]))
+        return m.check_kernel(k)
+    # the three documented experiments: spilled vector registers in the headline kernel (464 / 800 / 1 300)
+    v = bad(HEADLINE, vgpr_count=256, vgpr_spill_count=464, private_segment_fixed_size=220)
+    assert any("spills: 464 vector" in x for x in v) and any("220 bytes of scratch" in x for x in v)
+    # more than 256 registers (accumulation registers count): one wave per SIMD
+    v = bad(HEADLINE, vgpr_count=256, agpr_count=32)
+    assert len(v) == 1 and "288 vector registers" in v[0] and "1 wave(s) per SIMD instead of 2" in v[0]
+    assert bad(SWEEP, vgpr_count=244, private_segment_fixed_size=16)            # a scratch frame in a k-nearest sweep
+    assert bad(ONE_TILE, vgpr_count=256, private_segment_fixed_size=600) and not bad(ONE_TILE, vgpr_count=256, private_segment_fixed_size=200)
+    assert bad(SMALL_TILE, vgpr_count=140) and not bad(SMALL_TILE, vgpr_count=126)      # 64 x 64 tiles: four waves per SIMD
+    assert bad("_ZN12_GLOBAL__N_114u8_need_kernelEPKjll10HsdSegDescPj", vgpr_count=300, private_segment_fixed_size=4000) == []   # no rule: not judged
+
+
+def test_resource_check_on_the_built_library():
+    """The shipped library is within its contract (the same call build() makes)."""
+    import subprocess
+    import sys
+    lib = os.path.join(REPO, "hsd_amd", "libhsd_amd.so")
+    if not os.path.exists(lib):
+        import pytest
+        pytest.skip("library not built")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "hsd_amd", "csrc", "check_resources.py"), lib], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "within their register / scratch / LDS contract: ok" in p.stdout

@@ -42,7 +42,8 @@ class OracleEngine:
     def comm_init(self, world, rank, uid):
         self.comm_calls = getattr(self, "comm_calls", 0) + 1
         if os.environ.get("HSD_TEST_COMM_FAIL") and not os.environ.get("HSD_COMM_DRYRUN") and rank == world - 1:
-            raise RuntimeError("RCCL error: ncclCommInitRank: unhandled system error (test)")
+            from hsd_amd.engine import HsdError      # what Engine raises for a failed ncclCommInitRank (status HSD_ERR_COMM); a TypeError would propagate
+            raise HsdError("RCCL error: ncclCommInitRank: unhandled system error (test)")
         self.world, self.rank, self.has_comm = world, rank, not os.environ.get("HSD_COMM_DRYRUN")
     def comm_shard(self): return shard_rows(self.n, self.world, self.rank)
     def signature_allgather(self): raise AssertionError("the RCCL all-gather must not be reached after a failed communicator")
