@@ -175,7 +175,11 @@ struct hsd_ctx {
     uint32_t *d_tk_rmax16 = nullptr;   // [n_seg][npad / 16] members above the layer's threshold per 16-position granule (| bit 31: too wide for the uint8 range)
     int32_t *d_tk_gl = nullptr;        // [npad / 16] the positions' granules in natural order
     uint32_t *d_tk_tmaxs = nullptr;    // [n_seg][tk_nt] per-tile maxima of d_tk_rmax16
-    int tk_nf = 0, tk_nt = 0;
+    int tk_nf = 0, tk_nt = 0;          // features; tiles of ALL positions (tk_npos / 128: the graph's order, then -- a row block's call -- the block's rows)
+    // row block of the last setup (0, 0: the whole graph): its rows follow the graph's positions as a second run of positions, in the order the
+    // graph's k-d order gives them (a subsequence of it: 128 consecutive block rows span a contiguous run of the graph's tiles)
+    int64_t tk_blk0 = 0, tk_blk1 = 0, tk_npos = 0;
+    int32_t *d_tk_band_lo = nullptr, *d_tk_band_hi = nullptr;    // [block tiles] first / last tile of the graph's order the first launch paired a block tile with
     void *d_tk_list = nullptr;         // int2[tk_list_cap]: a launch's surviving tile pairs
     void *d_tk_band = nullptr;         // int2[tk_band_n]: the first launch's tiles (t, t) and (t, t + 1)
     int tk_list_cap = 0, tk_band_n = 0, tk_band_w = 1;
@@ -255,6 +259,8 @@ void hsd_khop_ms_release(hsd_ctx *ctx);
 void hsd_release_operands(hsd_ctx *ctx);
 void hsd_tk_release(hsd_ctx *ctx);
 int hsd_tk_order_device(hsd_ctx *ctx, const double *d_F, int64_t n, int nf, int32_t *d_order);      // csrc/tkorder.hip
+// positions (of the order d_orig[0 .. npos)) whose node lies in [r0, r1), ascending: d_pos[0 .. r1 - r0) (csrc/tkorder.hip); synchronises
+int hsd_tk_block_positions_device(hsd_ctx *ctx, const int32_t *d_orig, int64_t npos, int64_t r0, int64_t r1, int32_t *d_pos);
 extern "C" void hsd_heat_release_internal(hsd_ctx *ctx);
 int hsd_launch_pair_rowquirk_tiled(hsd_ctx *ctx, const double *psi_dev, int64_t ldpsi, int64_t r0, int64_t r1, double *dst, int64_t dld);
 int hsd_launch_pair_ragged_tiled(hsd_ctx *ctx, int layer_lo, int layer_hi, int64_t r0, int64_t r1, double *dst, int64_t dld);

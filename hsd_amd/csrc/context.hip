@@ -143,7 +143,10 @@ void hsd_tk_release(hsd_ctx *ctx) {
     ctx->d_tk_list = ctx->d_tk_band = nullptr;
     hsd_dev_free(ctx->d_tk_count);
     hsd_dev_free(ctx->d_tk_tmax);
+    hsd_dev_free(ctx->d_tk_band_lo);
+    hsd_dev_free(ctx->d_tk_band_hi);
     ctx->tk_ready = false;
+    ctx->tk_blk0 = ctx->tk_blk1 = ctx->tk_npos = 0;
     ctx->tk_list_cap = ctx->tk_band_n = ctx->tk_nf = ctx->tk_nt = 0;
 }
 

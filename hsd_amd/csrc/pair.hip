@@ -1426,7 +1426,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                         const double v = ACC(r, cc);
                         if (v <= ti_ && i != j) {
                             const int jo = a.orig_of ? a.orig_of[j] : (int)j;       // (permuted operands: the list holds original node ids)
-                            if (jo >= 0) {
+                            // (a row block's rows are extra positions behind the graph's: the row's own node is one of the columns)
+                            if (jo >= 0 && !(a.self_by_orig && jo == a.orig_of[i])) {
                                 const int slot = atomicAdd(a.cand_cnt + i, 1);
                                 if (slot < a.cand_cap) { a.cand_idx[i * a.cand_cap + slot] = jo; a.cand_val[i * a.cand_cap + slot] = v; }
                             }
@@ -1749,21 +1750,25 @@ __global__ void tk_tilemax_kernel(const uint16_t *__restrict__ tau16, int ntiles
 // features of the gap between their intervals) against the larger of the two tiles' largest thresholds.  drop_band > 0: pairs |ti - tj| <= drop_band
 // are dropped as well (the first launch of the pruned sweep has already evaluated them).  The order of the output is whatever the
 // atomics give: the sweep's results are sets.
+// Row block (rows_only): the list's tiles are relative to the region -- row tile ti is tile ti_off + ti of the intervals, column tile tj is
+// tj_off + tj --, only the rows carry thresholds, and the first launch's pairs are the column tiles [band_lo[ti], band_hi[ti]] of row tile ti.
 __global__ void tk_filter_kernel(const int2 *__restrict__ in, int n_in, const double *__restrict__ lo, const double *__restrict__ hi,
                                  const double *__restrict__ scale, int nf, int nt,
-                                 const uint16_t *__restrict__ tmax, int drop_band, int2 *__restrict__ out, int *__restrict__ count) {
+                                 const uint16_t *__restrict__ tmax, int drop_band, int ti_off, int tj_off, int rows_only,
+                                 const int32_t *__restrict__ band_lo, const int32_t *__restrict__ band_hi, int2 *__restrict__ out, int *__restrict__ count) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_in) return;
     const int2 t = in[k];
-    const int ti = t.x & TILE_INDEX_MASK, tj = t.y;
-    if (drop_band && abs(tj - ti) <= drop_band) return;
+    const int ti = (t.x & TILE_INDEX_MASK) + ti_off, tj = t.y + tj_off;
+    if (band_lo) { if (tj >= band_lo[ti - ti_off] && tj <= band_hi[ti - ti_off]) return; }
+    else if (drop_band && abs(tj - ti) <= drop_band) return;
     double lb = 0.0;
     for (int f = 0; f < nf; ++f) {
         const double a0 = lo[(int64_t)f * nt + ti], a1 = hi[(int64_t)f * nt + ti], b0 = lo[(int64_t)f * nt + tj], b1 = hi[(int64_t)f * nt + tj];
         // (zero-pad layers: the gap between the rings' value sums, divided by the larger ring -- at least the smaller of the tiles' smallest 1 / ring size)
         lb += fmax(0.0, fmax(a0 - b1, b0 - a1)) * (scale ? fmin(scale[(int64_t)f * nt + ti], scale[(int64_t)f * nt + tj]) : 1.0);
     }
-    const unsigned m = max((unsigned)tmax[ti], (unsigned)tmax[tj]);
+    const unsigned m = rows_only ? (unsigned)tmax[ti] : max((unsigned)tmax[ti], (unsigned)tmax[tj]);
     const double thr = (double)__uint_as_float(m << 16);
     // (the bound and the kernel's distances are sums of the same terms in different orders: a relative 1e-9 covers the rounding of both)
     if (lb * (1.0 - 1e-9) - 1e-9 <= thr) out[atomicAdd(count, 1)] = t;
@@ -1855,6 +1860,15 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
             LI.d_gl = const_cast<int32_t *>(a.gl_ov); LI.d_tmax = const_cast<uint32_t *>(a.tmax_ov); LI.ntiles = a.ntl_ov;
             LJ = LI;
             ok = a.sym != 0;
+            if (!a.sym) {
+                // (a row block's sweep: rows and columns are two runs of whole tiles of the same position space; the tmax rows keep the
+                //  stride of the whole list -- b.ntl_i / b.ntl_j below)
+                ok = a.i_begin % 128 == 0 && a.j_begin % 128 == 0 && i_full == a.i_end && j_full == a.j_end && a.i_end <= (int64_t)a.ntl_ov * 128 &&
+                     a.j_end <= (int64_t)a.ntl_ov * 128;
+                LI.d_gl += 8 * (a.i_begin / 128); LJ.d_gl += 8 * (a.j_begin / 128);
+                if (LI.d_tmax) { LI.d_tmax += a.i_begin / 128; LJ.d_tmax += a.j_begin / 128; }
+                LI.ntiles = (int)((a.i_end - a.i_begin) / 128); LJ.ntiles = (int)((a.j_end - a.j_begin) / 128);
+            }
         } else {
             ok = gran_list(ctx, a.i_begin, i_full, stream, &LI);
             if (ok) { if (a.sym) LJ = LI; else ok = gran_list(ctx, a.j_begin, j_full, stream, &LJ); }
@@ -1888,6 +1902,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                 b.gl_i = LI.d_gl; b.gl_j = LJ.d_gl;
                 b.tmax_i = LI.d_tmax; b.tmax_j = LJ.d_tmax;
                 b.ntl_i = LI.ntiles; b.ntl_j = LJ.ntiles;
+                if (a.gl_ov) b.ntl_i = b.ntl_j = a.ntl_ov;
                 b.suf = a.suf ? a.suf : ctx->d_suf;
                 b.stamps = nullptr;
                 if (a.tau) {
@@ -1897,14 +1912,21 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     hipLaunchKernelGGL(tau_bf16_up_kernel, dim3((unsigned)((a.i_end - a.i_begin + 255) / 256)), dim3(256), 0, stream, a.tau, a.i_begin, a.i_end,
                                        const_cast<uint16_t *>(a.tau16));
                 }
+                // (a pruned sweep whose filter cannot run would re-evaluate the first launch's tile pairs and append their candidates twice:
+                //  refuse -- hsd_pair_topk then runs the unpruned sweep)
+                if (a.tau && a.prune_lo && n_in > 0 && !(l_in && ctx->d_tk_list && n_in <= ctx->tk_list_cap))
+                    return hsd_fail(ctx, HSD_ERR_INTERNAL, "pruned k-nearest sweep: the tile filter cannot run (%d tile pairs, list of %d)", n_in, ctx->tk_list_cap);
                 if (a.tau && a.prune_lo && l_in && n_in > 0 && ctx->d_tk_list && n_in <= ctx->tk_list_cap) {
                     // pruned sweep: drop the tile pairs that no row's CURRENT threshold can reach (tk_filter_kernel); the count comes
                     // back to the host -- one small synchronisation per launch of the sweep
                     int kept = 0;
-                    hipLaunchKernelGGL(tk_tilemax_kernel, dim3((unsigned)a.prune_nt), dim3(64), 0, stream, a.tau16 + a.i_begin, a.prune_nt, ctx->d_tk_tmax);
+                    // (largest threshold of every row tile: the region's rows; a row block's tiles sit behind the graph's in the intervals' numbering)
+                    const int row_tiles = (int)((a.i_end - a.i_begin) / 128), ti_off = a.sym ? 0 : (int)(a.i_begin / 128), tj_off = a.sym ? 0 : (int)(a.j_begin / 128);
+                    hipLaunchKernelGGL(tk_tilemax_kernel, dim3((unsigned)row_tiles), dim3(64), 0, stream, a.tau16 + a.i_begin, row_tiles, ctx->d_tk_tmax + a.i_begin / 128);
                     e = hipMemsetAsync(ctx->d_tk_count, 0, sizeof(int), stream);
                     hipLaunchKernelGGL(tk_filter_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, l_in, n_in, a.prune_lo, a.prune_hi, a.prune_scale, a.prune_nf,
-                                       a.prune_nt, ctx->d_tk_tmax, a.prune_drop_band, reinterpret_cast<int2 *>(ctx->d_tk_list), ctx->d_tk_count);
+                                       a.prune_nt, ctx->d_tk_tmax, a.prune_drop_band, ti_off, tj_off, a.mirror ? 0 : 1, a.prune_band_lo, a.prune_band_hi,
+                                       reinterpret_cast<int2 *>(ctx->d_tk_list), ctx->d_tk_count);
                     if (e == hipSuccess) e = hipMemcpyAsync(&kept, ctx->d_tk_count, sizeof(int), hipMemcpyDeviceToHost, stream);
                     if (e == hipSuccess) e = hipStreamSynchronize(stream);
                     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "k-nearest tile filter: %s", hipGetErrorString(e));
@@ -1968,6 +1990,7 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
         }
         // (a list could not be built: fall through to the one-tile kernel over every tile)
     }
+    if (a.gl_ov || a.orig_of) return hsd_fail(ctx, HSD_ERR_INTERNAL, "permuted operands need the persistent kernel (a tile list could not be built)");
     if (BT == 128 && !hsd_hook(H_TILE) && ctx->mode != PAIR_ZP_F64) {
         // few tiles per CU: the small tile's five workgroups per CU overlap their phases better than two large ones
         // (ER N = 10k, raw fp64 W1: 0.321 ms with 64 x 64 tiles against 0.351 ms with 128 x 128)

@@ -90,6 +90,12 @@ struct PairArgs {
     const double *prune_lo, *prune_hi;   // host side only: [prune_nf][prune_nt]
     const double *prune_scale;      // host side only: [prune_nf][prune_nt] smallest factor of the feature's gap within a tile (nullptr: 1)
     int prune_nf, prune_nt, prune_drop_band;
+    // ... of a ROW BLOCK (hsd_pair_topk(k, r0, r1), a rank's share): the block's rows are a second run of positions behind the graph's
+    // (rows [i_begin, i_end) x columns [j_begin, j_end), not symmetric, not mirrored); a row's own node also sits among the columns, so
+    // "not itself" is decided on the ORIGINAL ids (kernel: self_by_orig); the first launch paired row tile t with the column tiles
+    // [prune_band_lo[t], prune_band_hi[t]], which the filter of the later launches drops (host side)
+    int self_by_orig;
+    const int32_t *prune_band_lo, *prune_band_hi;
     const int32_t *gl_ov;           // host side only: the region's granule list and its per-tile maxima given by the caller (permuted operands)
     const uint32_t *tmax_ov;
     int ntl_ov;

@@ -70,13 +70,13 @@ __global__ void tk_feature_combine_kernel(const double *__restrict__ P, int64_t 
     if (H) F[(int64_t)nfh * n + i] = H[i];
 }
 
-// Xp[c][p] = X[c][orig[p]] (0 at padding positions); blockIdx.y = column
-__global__ void tk_gather_kernel(const double *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, double *__restrict__ Xp) {
+// Xp[c][p] = X[c][orig[p]] (0 at padding positions), p < npos positions (stride npos), X with node stride npad; blockIdx.y = column
+__global__ void tk_gather_kernel(const double *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, int64_t npos, double *__restrict__ Xp) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npad) return;
+    if (p >= npos) return;
     const int32_t o = orig[p];
     const int64_t c = blockIdx.y;
-    Xp[c * npad + p] = o >= 0 ? X[c * npad + o] : 0.0;
+    Xp[c * npos + p] = o >= 0 ? X[c * npad + o] : 0.0;
 }
 
 // thresholds by node -> thresholds by position (0 at padding positions: nothing is at distance <= 0 from them but themselves)
@@ -85,6 +85,12 @@ __global__ void tk_permute_tau_kernel(const int32_t *__restrict__ orig, int64_t 
     if (p >= npos) return;
     const int32_t o = orig[p];
     tau_pos[p] = o >= 0 ? tau_node[o] : 0.0;
+}
+
+// thresholds of +inf for the positions of real nodes, 0 for padding positions (their rows collect nothing and never hold a tile's threshold open)
+__global__ void tk_tau_open_kernel(const int32_t *__restrict__ orig, int64_t npos, double *__restrict__ tau_pos) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npos) tau_pos[p] = orig[p] >= 0 ? (double)INFINITY : 0.0;
 }
 
 // out[orig[p]] = in[p] for the rows p of real nodes (k entries per row)
@@ -375,12 +381,18 @@ __global__ void tk_feature_seg_kernel(const uint32_t *__restrict__ X, int64_t np
 }
 
 // Up[c][p] = U[c][orig[p]] (0 at padding positions), 32-bit words; blockIdx.y = column / row
-__global__ void tk_gather_u32_kernel(const uint32_t *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, uint32_t *__restrict__ Xp) {
+__global__ void tk_gather_u32_kernel(const uint32_t *__restrict__ X, int64_t npad, const int32_t *__restrict__ orig, int64_t npos, uint32_t *__restrict__ Xp) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npad) return;
+    if (p >= npos) return;
     const int32_t o = orig[p];
     const int64_t c = blockIdx.y;
-    Xp[c * npad + p] = o >= 0 ? X[c * npad + o] : 0u;
+    Xp[c * npos + p] = o >= 0 ? X[c * npad + o] : 0u;
+}
+
+// a row block's positions: orig_ext[npad + q] = orig[pos[q]], q < m (the rest of the block's last tile stays -1)
+__global__ void tk_block_orig_kernel(const int32_t *__restrict__ orig, const int32_t *__restrict__ pos, int64_t m, int32_t *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < m) out[q] = orig[pos[q]];
 }
 
 // members above a layer's threshold per POSITION, recovered from the permuted operands: the non-zero rank values of the stored rank words, and
@@ -446,9 +458,12 @@ __global__ void tk_tile_interval_kernel(const double *__restrict__ V, const doub
     }
 }
 
-int tk_prepare(hsd_ctx *ctx) {
-    if (ctx->tk_ready) return HSD_OK;
-    hsd_tk_release(ctx);                               // (whatever an earlier, failed attempt allocated)
+// [b0, b1): the row block the sweep is for (b0 == b1 == 0: the whole graph).  The permuted operand set then has a second run of positions behind
+// the graph's npad: the block's rows in the order the graph's k-d order gives them (a subsequence of it), padded to whole tiles -- the sweep's
+// rows; its columns are the graph's positions.  One setup is kept per prepared distance: the last block asked for.
+int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
+    if (ctx->tk_ready && ctx->tk_blk0 == b0 && ctx->tk_blk1 == b1) return HSD_OK;
+    hsd_tk_release(ctx);                               // (another block's setup, or whatever an earlier, failed attempt allocated)
     const bool verbose = hsd_hook(H_TOPK_VERBOSE) != nullptr;
     if (verbose) (void)hipStreamSynchronize(ctx->stream);          // (whatever hsd_pair_prepare left in flight is not this setup's time)
     auto t_last = std::chrono::steady_clock::now();
@@ -463,7 +478,8 @@ int tk_prepare(hsd_ctx *ctx) {
     const bool seg = ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32;
     const bool pack = ctx->mode == PAIR_SAD_U16;
     if (npad % 128 != 0) return hsd_fail(ctx, HSD_ERR_INVALID, "pruned k-nearest sweep: operand stride is no whole number of tiles");
-    const int nt = (int)(npad / 128);
+    const int64_t bm = b1 - b0, bpad = (bm + 127) / 128 * 128, npos = npad + bpad;     // positions: the graph's order, then the block's rows
+    const int nt = (int)(npos / 128), nt_graph = (int)(npad / 128);
     // bound features V[f][i] with their factors S[f][i] (1 for the raw distance and the ring-0 value; 1 / ring size for a zero-pad layer: the
     // layer's distance is at least |V_i - V_j| min(S_i, S_j)); the nodes are ordered on V * S
     int nf = 0, nlay = 0;
@@ -507,7 +523,24 @@ int tk_prepare(hsd_ctx *ctx) {
     }
     mark("features");
     int rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npad))) return rc;
+    // the block's rows behind the graph's positions: the positions of the graph's order that hold a node of [b0, b1), ascending (their nodes
+    // -> d_tk_orig[npad ...]; the positions themselves -> the host, for the first launch's tile list)
+    std::vector<int32_t> block_pos;
+    const auto block_positions = [&]() -> int {
+        if (bm == 0) return HSD_OK;
+        DevTmp dpos;
+        HSD_TMP_ALLOC(ctx, dpos, (size_t)bm * sizeof(int32_t));
+        const int r = hsd_tk_block_positions_device(ctx, ctx->d_tk_orig, npad, b0, b1, dpos.as<int32_t>());
+        if (r) return r;
+        hipLaunchKernelGGL(tk_block_orig_kernel, dim3((unsigned)((bm + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t *)ctx->d_tk_orig, (const int32_t *)dpos.as<int32_t>(), bm,
+                           ctx->d_tk_orig + npad);
+        block_pos.resize((size_t)bm);
+        HSD_HIP(ctx, hipMemcpyAsync(block_pos.data(), dpos.p, (size_t)bm * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        mark("block rows in the graph's order");
+        return HSD_OK;
+    };
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npos))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, (size_t)nf * nt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, (size_t)nf * nt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_scale, (size_t)nf * nt))) return rc;
@@ -521,9 +554,10 @@ int tk_prepare(hsd_ctx *ctx) {
                                npad, n, nlay, dFo.as<double>());
             Fo = dFo.as<double>();
         }
-        HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_orig, 0xff, (size_t)npad * sizeof(int32_t), ctx->stream));          // padding positions: -1
+        HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_orig, 0xff, (size_t)npos * sizeof(int32_t), ctx->stream));          // padding positions: -1
         if ((rc = hsd_tk_order_device(ctx, Fo, n, nf, ctx->d_tk_orig))) return rc;
         mark("k-d order (device)");
+        if ((rc = block_positions())) return rc;
         hipLaunchKernelGGL(tk_tile_interval_kernel, dim3((unsigned)nt, (unsigned)nf), dim3(128), 0, ctx->stream, dV.as<double>(), seg ? (const double *)ctx->d_inv : nullptr,
                            npad, n, seg ? nlay : 0, (const int32_t *)ctx->d_tk_orig, nt, ctx->d_tk_lo, ctx->d_tk_hi, ctx->d_tk_scale);
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (dFo goes)
@@ -535,68 +569,95 @@ int tk_prepare(hsd_ctx *ctx) {
             kd_order_host(Fo, n, nf, idx);
         }
         mark("k-d order (host)");
-        std::vector<int32_t> orig((size_t)npad, -1);
+        std::vector<int32_t> orig((size_t)npos, -1);
         std::copy(idx.begin(), idx.end(), orig.begin());
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if ((rc = block_positions())) return rc;
+        if (bm > 0) HSD_HIP(ctx, hipMemcpy(orig.data() + npad, ctx->d_tk_orig + npad, (size_t)bpad * sizeof(int32_t), hipMemcpyDeviceToHost));
         std::vector<double> flo((size_t)nf * nt, INFINITY), fhi((size_t)nf * nt, -INFINITY), fsc((size_t)nf * nt, INFINITY);
-        for (int64_t p = 0; p < n; ++p)
-            for (int f = 0; f < nf; ++f) {
-                const size_t src = (size_t)f * n + idx[(size_t)p], dst = (size_t)f * nt + p / 128;
+        for (int64_t p = 0; p < npos; ++p)
+            for (int f = 0; f < nf && orig[(size_t)p] >= 0; ++f) {
+                const size_t src = (size_t)f * n + orig[(size_t)p], dst = (size_t)f * nt + p / 128;
                 flo[dst] = std::min(flo[dst], V[src]); fhi[dst] = std::max(fhi[dst], V[src]);
                 fsc[dst] = std::min(fsc[dst], seg ? S[src] : 1.0);
             }
-        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_orig, orig.data(), orig.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HSD_HIP(ctx, hipMemcpy(ctx->d_tk_lo, flo.data(), flo.size() * sizeof(double), hipMemcpyHostToDevice));
         HSD_HIP(ctx, hipMemcpy(ctx->d_tk_hi, fhi.data(), fhi.size() * sizeof(double), hipMemcpyHostToDevice));
         HSD_HIP(ctx, hipMemcpy(ctx->d_tk_scale, fsc.data(), fsc.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     const int band_w = std::max(1, std::min(4, hsd_hook_int(H_TOPK_BAND, 1)));      // the first launch: every tile with itself and its band_w successors
     std::vector<int2> band;
-    for (int t = 0; t < nt; ++t)
-        for (int d = 0; d <= band_w && t + d < nt; ++d) band.push_back(make_int2(t, t + d));
+    if (bm == 0) {
+        for (int t = 0; t < nt; ++t)
+            for (int d = 0; d <= band_w && t + d < nt; ++d) band.push_back(make_int2(t, t + d));
+    } else {
+        // a row block: block tile t (its rows are consecutive members of the graph's order) with the graph's tiles its rows sit in and band_w more
+        // on either side -- tile indices RELATIVE to the region (rows: the block's tiles; columns: the graph's), as the region's lists are
+        const int bt = (int)(bpad / 128);
+        std::vector<int32_t> blo((size_t)bt), bhi((size_t)bt);
+        for (int t = 0; t < bt; ++t) {
+            const int64_t q0 = (int64_t)t * 128, q1 = std::min<int64_t>(bm, q0 + 128) - 1;
+            blo[(size_t)t] = std::max(0, block_pos[(size_t)q0] / 128 - band_w);
+            bhi[(size_t)t] = std::min(nt_graph - 1, block_pos[(size_t)q1] / 128 + band_w);
+            for (int c = blo[(size_t)t]; c <= bhi[(size_t)t]; ++c) band.push_back(make_int2(t, c));
+        }
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_band_lo, (size_t)bt))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_band_hi, (size_t)bt))) return rc;
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band_lo, blo.data(), blo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band_hi, bhi.data(), bhi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     ctx->tk_band_w = band_w;
     mark("tile intervals + first-launch list");
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npad))) return rc;
+    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npos))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
-    ctx->tk_list_cap = (int)std::min<int64_t>((int64_t)nt * (nt + 1) / 2, 0x7fffffff);
+    ctx->tk_list_cap = (int)std::min<int64_t>(bm == 0 ? (int64_t)nt * (nt + 1) / 2 : (bpad / 128) * (int64_t)nt_graph, 0x7fffffff);
     HSD_HIP(ctx, hipMalloc(&ctx->d_tk_list, (size_t)ctx->tk_list_cap * sizeof(int2)));
     HSD_HIP(ctx, hipMalloc(&ctx->d_tk_band, band.size() * sizeof(int2)));
     ctx->tk_band_n = (int)band.size();
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
-    const dim3 pgrid((unsigned)((npad + 255) / 256));
+    const dim3 pgrid((unsigned)((npos + 255) / 256));
     if (ctx->has_point)
-        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, ctx->d_tk_H);
+        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, npos, ctx->d_tk_H);
     if (!seg) {
         const int cols = std::max(ctx->dcols, 16);
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, (size_t)cols * npad))) return rc;
-        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, ctx->d_tk_orig, ctx->d_tk_X);
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, (size_t)cols * npos))) return rc;
+        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, ctx->d_tk_orig, npos, ctx->d_tk_X);
+        if (bm > 0) {
+            // (a row block's rectangle names its tiles by the positions' own granule list -- the graph's list ends with the graph)
+            const int ngran16 = (int)(npos / 16);
+            if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
+            std::vector<int32_t> gl((size_t)ngran16);
+            for (int g = 0; g < ngran16; ++g) gl[(size_t)g] = g;
+            HSD_HIP(ctx, hipMemcpy(ctx->d_tk_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     } else {
         // the zero-pad kinds' operands: packed words, 1 / ring size per layer, suffix sums -- and, recovered from them, what the tile planner reads:
         // members above each layer's threshold per position -> maxima per 16-position granule (+ the "too wide for the uint8 range" flags) -> per tile
-        const int cols = std::max(ctx->dcols, 32), ngran16 = (int)(npad / 16);
+        const int cols = std::max(ctx->dcols, 32), ngran16 = (int)(npos / 16);
         const int64_t sufr = (int64_t)ctx->suf_rows + 1;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_U, (size_t)cols * npad))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_inv, (size_t)nlay * npad))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_suf, (size_t)sufr * npad))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_U, (size_t)cols * npos))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_inv, (size_t)nlay * npos))) return rc;
+        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_suf, (size_t)sufr * npos))) return rc;
         if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_rmax16, (size_t)nlay * ngran16))) return rc;
         if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
         if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmaxs, (size_t)nlay * nt))) return rc;
-        hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, ctx->d_tk_orig, ctx->d_tk_U);
-        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, (const double *)ctx->d_inv, npad, ctx->d_tk_orig, ctx->d_tk_inv);
-        if (ctx->d_suf) hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)sufr), dim3(256), 0, ctx->stream, ctx->d_suf, npad, ctx->d_tk_orig, ctx->d_tk_suf);
-        else HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_suf, 0, (size_t)sufr * npad * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, ctx->d_tk_orig, npos, ctx->d_tk_U);
+        hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, (const double *)ctx->d_inv, npad, ctx->d_tk_orig, npos, ctx->d_tk_inv);
+        if (ctx->d_suf) hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)sufr), dim3(256), 0, ctx->stream, ctx->d_suf, npad, ctx->d_tk_orig, npos, ctx->d_tk_suf);
+        else HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_suf, 0, (size_t)sufr * npos * sizeof(uint32_t), ctx->stream));
         DevTmp dR, dneed;
-        HSD_TMP_ALLOC(ctx, dR, (size_t)nlay * npad * sizeof(uint32_t));
-        HSD_TMP_ALLOC(ctx, dneed, (size_t)2 * npad * sizeof(uint32_t));
-        if (pack) hipLaunchKernelGGL(tk_rnode_kernel<true>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npad, ctx->d_seg_tab, dR.as<uint32_t>());
-        else hipLaunchKernelGGL(tk_rnode_kernel<false>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npad, ctx->d_seg_tab, dR.as<uint32_t>());
-        hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, dR.as<uint32_t>(), npad, ngran16, ctx->d_tk_rmax16);
+        HSD_TMP_ALLOC(ctx, dR, (size_t)nlay * npos * sizeof(uint32_t));
+        HSD_TMP_ALLOC(ctx, dneed, (size_t)2 * npos * sizeof(uint32_t));
+        if (pack) hipLaunchKernelGGL(tk_rnode_kernel<true>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npos, ctx->d_seg_tab, dR.as<uint32_t>());
+        else hipLaunchKernelGGL(tk_rnode_kernel<false>, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, ctx->d_tk_U, ctx->d_tk_suf, npos, ctx->d_seg_tab, dR.as<uint32_t>());
+        hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)nlay), dim3(256), 0, ctx->stream, dR.as<uint32_t>(), npos, ngran16, ctx->d_tk_rmax16);
         for (int s2 = 0; s2 < nlay && pack; ++s2) {
             const HsdSegDesc &d = ctx->seg_tab[s2];
             if (d.r8_col0 < 0) continue;
-            HSD_HIP(ctx, hipMemsetAsync(dneed.p, 0, (size_t)2 * npad * sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(u8_need_kernel, dim3(pgrid.x), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_tk_U, npad, npad, d, dneed.as<uint32_t>());
-            hipLaunchKernelGGL(tk_wide_kernel, dim3((unsigned)((ngran16 + 255) / 256)), dim3(256), 0, ctx->stream, dneed.as<uint32_t>(), npad, ngran16, d.r8_k16 - d.r8_r16, d.r8_r16,
+            HSD_HIP(ctx, hipMemsetAsync(dneed.p, 0, (size_t)2 * npos * sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(u8_need_kernel, dim3(pgrid.x), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_tk_U, npos, npos, d, dneed.as<uint32_t>());
+            hipLaunchKernelGGL(tk_wide_kernel, dim3((unsigned)((ngran16 + 255) / 256)), dim3(256), 0, ctx->stream, dneed.as<uint32_t>(), npos, ngran16, d.r8_k16 - d.r8_r16, d.r8_r16,
                                ctx->d_tk_rmax16 + (size_t)s2 * ngran16);
         }
         std::vector<int32_t> gl((size_t)ngran16);
@@ -609,25 +670,32 @@ int tk_prepare(hsd_ctx *ctx) {
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     mark("allocations + permuted operands");
     ctx->tk_nf = nf; ctx->tk_nt = nt;
+    ctx->tk_blk0 = b0; ctx->tk_blk1 = b1; ctx->tk_npos = npos;
     ctx->tk_ready = true;
     return HSD_OK;
 }
 
-// *done = false: not applicable (or a list overflowed): the caller runs the unpruned sweep
-int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *done) {
+// *done = false: not applicable (or a list overflowed): the caller runs the unpruned sweep.
+// [r0, r1): the rows asked for.  The whole graph is one symmetric, mirrored sweep over the graph's positions.  A ROW BLOCK (a rank's share of
+// `--gpus P`) is a rectangle: its rows -- a second run of positions behind the graph's, in the graph's order -- against
+// ALL columns, row lists only; a pair inside the block is evaluated from both of its rows, as the matrix's row blocks evaluate it, and every
+// rank's work is rows x n pairs under the same pruning (the thresholds, the lists and so the results are those of the unpruned call).
+int topk_pruned(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, double *dist_out, bool *done) {
     *done = false;
     const int64_t n = ctx->n, npad = ctx->npad;
+    const bool block = !(r0 == 0 && r1 == n);
+    const int64_t bm = block ? r1 - r0 : 0, bpad = (bm + 127) / 128 * 128, npos = npad + bpad;
     const bool seg = ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32;
     PairArgs a{};
-    a.npad = npad;
+    a.npad = npos;
     a.dcols = ctx->dcols;
     a.n_seg = seg ? ctx->n_seg : 0;
     a.list_cap = ctx->list_cap;
     a.dcols_valid = ctx->dcols_alg;
     { const char *e = hsd_hook(H_TOPK_DEBUG); a.dbg = e ? atoi(e) : 0; }
     a.rbase = 0;
-    a.i_begin = 0; a.i_end = npad; a.j_begin = 0; a.j_end = npad;
-    a.sym = 1; a.mirror = 1;
+    if (!block) { a.i_begin = 0; a.i_end = npad; a.j_begin = 0; a.j_end = npad; a.sym = 1; a.mirror = 1; }
+    else { a.i_begin = npad; a.i_end = npos; a.j_begin = 0; a.j_end = npad; a.sym = 0; a.mirror = 0; a.self_by_orig = 1; }
     {
         // the persistent kernel must take the region (its LDS budget: at most three per-node vectors)
         if (a.n_seg + (ctx->has_point ? 1 : 0) > 3) return HSD_OK;
@@ -635,7 +703,7 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
         probe.tau = reinterpret_cast<const double *>(ctx);          // (any non-null value: the k-nearest kernels have no output alignment to check)
         if (!stream_waves(ctx, probe)) return HSD_OK;
     }
-    int rc = tk_prepare(ctx);
+    int rc = tk_prepare(ctx, block ? r0 : 0, block ? r1 : 0);
     if (rc) return rc;
     if (seg) {
         a.X = a.Y = ctx->d_tk_U;
@@ -647,18 +715,22 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
         a.gl_ov = ctx->d_tk_gl; a.tmax_ov = ctx->d_tk_tmaxs; a.ntl_ov = ctx->tk_nt;
     } else {
         a.X = a.Y = ctx->d_tk_X;
+        // (the fp64 kind has no per-tile maxima, but a row block's rectangle still takes its tile composition from the positions' own list)
+        if (block) { a.gl_ov = ctx->d_tk_gl; a.tmax_ov = nullptr; a.ntl_ov = ctx->tk_nt; }
     }
     a.point = ctx->has_point ? ctx->d_tk_H : nullptr;
     a.orig_of = ctx->d_tk_orig;
-    const int64_t rows = npad;
+    // rows of the sweep: positions [p0, p0 + rows); the per-row arrays below hold `rows` entries and are addressed by position (pointers moved
+    // back by p0, as the unpruned sweep of a row block does with its node range)
+    const int64_t p0 = block ? npad : 0, rows = block ? bpad : npad, out_rows = block ? bm : n;
     const int64_t cap = std::max<int64_t>(2048, 512 + 8 * (int64_t)k);
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t oTau = carve((size_t)rows * sizeof(double)), oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
     const size_t oVal = carve((size_t)rows * cap * sizeof(double)), oOi = carve((size_t)rows * k * sizeof(int)), oOv = carve((size_t)rows * k * sizeof(double));
-    const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64), oFi = carve((size_t)n * k * sizeof(int)), oFv = carve((size_t)n * k * sizeof(double));
+    const size_t oT16 = carve((size_t)rows * sizeof(uint16_t) + 64), oFi = carve((size_t)out_rows * k * sizeof(int)), oFv = carve((size_t)out_rows * k * sizeof(double));
     const int64_t M = std::min<int64_t>(n, 1024), ldS = (M + 127) / 128 * 128;
-    const size_t oS = carve((size_t)n * ldS * sizeof(double)), oTn = carve((size_t)n * sizeof(double));
+    const size_t oS = carve((size_t)out_rows * ldS * sizeof(double)), oTn = carve((size_t)out_rows * sizeof(double));
     if (ctx->scratch_bytes < off) {
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -680,8 +752,15 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
     // BA N = 100k: lists of 38 000 entries).  Part two, the tiles next to a row's own, only tightens it.  The raw fp64 distance starts from
     // +inf: its lists stay short without the sample (longest 709 of 2 048 at BA N = 100k, 27 000 soak calls), which would cost it 4.4 ms
     // of arithmetic + 0.8 GB of sample matrix per call (66.7 -> 74.4 ms, measured).
-    if (!seg) hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_tau, rows, (double)INFINITY);
+    // A ROW BLOCK samples for both kinds: 128 consecutive block rows span as many of the graph's tiles as the block is thin there (the oldest
+    // rows of a scale-free graph are its hubs: dense in a few tiles, one in fifty elsewhere), and under thresholds of +inf a wide first launch
+    // overflows the lists (seen: a row tile across 17 tiles = 2 176 candidates per row against a capacity of 2 048; rows whose lists overflowed
+    // keep +inf and collect the whole graph).  With sampled thresholds the first launch is filtered like the later ones.
+    const bool sample = seg || block;
+    if (!sample) hipLaunchKernelGGL(tk_tau_open_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t *)ctx->d_tk_orig + p0, rows, d_tau);
     else {
+        // (rows [q0, q1) of the natural order: the whole graph, or the block; S and tauN hold these rows only)
+        const int64_t q0 = block ? r0 : 0, q1 = block ? r1 : n;
         double *d_S = reinterpret_cast<double *>(base + oS), *d_tauN = reinterpret_cast<double *>(base + oTn);
         PairArgs nat{};
         nat.X = ctx->d_X; nat.Y = ctx->d_X;
@@ -691,7 +770,7 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
         nat.seg_tab = reinterpret_cast<const SegDesc *>(ctx->d_seg_tab);
         nat.rmax = ctx->d_rmax; nat.ngran = ctx->ngran; nat.list_cap = ctx->list_cap;
         nat.dcols_valid = ctx->dcols_alg;
-        nat.rbase = 0; nat.i_begin = 0; nat.i_end = n;
+        nat.rbase = q0; nat.i_begin = q0; nat.i_end = q1;
         const int n_sub = (int)((M + 127) / 128);
         const int64_t n_tiles_total = (n + 127) / 128;
         for (int t = 0; t < n_sub; ++t) {
@@ -703,27 +782,30 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
             sub.ld = ldS;
             if ((rc = launch_region(ctx, sub, tile_edge(ctx), ctx->stream))) return rc;
             if (sub.j_end - sub.j_begin < 128)
-                hipLaunchKernelGGL(fill_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_S, ldS, n, (int)(t * 128 + (sub.j_end - sub.j_begin)),
+                hipLaunchKernelGGL(fill_columns_kernel, dim3((unsigned)((q1 - q0 + 255) / 256)), dim3(256), 0, ctx->stream, d_S, ldS, q1 - q0, (int)(t * 128 + (sub.j_end - sub.j_begin)),
                                    (int)((t + 1) * 128), (double)INFINITY);
         }
-        hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, n_sub * 128, (int64_t)0, n, k, 0.0, d_tauN);
-        hipLaunchKernelGGL(tk_permute_tau_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig, rows, d_tauN, d_tau);
+        hipLaunchKernelGGL(topk_threshold_kernel, dim3((unsigned)((q1 - q0 + 3) / 4)), dim3(256), 0, ctx->stream, d_S, ldS, n_sub * 128, (int64_t)0, q1 - q0, k, 0.0, d_tauN);
+        hipLaunchKernelGGL(tk_permute_tau_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig + p0, rows, d_tauN - q0, d_tau);
     }
     PairArgs b = a;
-    b.tau = d_tau; b.cand_cnt = d_cnt; b.cand_idx = d_idx; b.cand_val = d_val; b.cand_cap = (int)cap;
-    b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16);
+    b.tau = d_tau - p0; b.cand_cnt = d_cnt - p0; b.cand_idx = d_idx - p0 * cap; b.cand_val = d_val - p0 * cap; b.cand_cap = (int)cap;
+    b.tau16 = reinterpret_cast<const uint16_t *>(base + oT16) - p0;
     const int BT = tile_edge(ctx);
     const size_t cmp_lds = (size_t)4 * k * 12;
-    // launch 0: every row against the tiles next to its own in the order, under thresholds of +inf; then the first real thresholds
+    // launch 0: every row against the tiles next to its own in the order, under thresholds of +inf (a row block: under the sampled thresholds,
+    // and filtered by them); then the first real thresholds
     b.explicit_tiles = reinterpret_cast<const int2 *>(ctx->d_tk_band); b.n_explicit = ctx->tk_band_n;
+    if (block) { b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_scale = seg ? ctx->d_tk_scale : nullptr; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = 0; }
     if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
     // the rest of the pair space in anti-diagonal phases, each filtered against the thresholds of the moment (tightened after phases 1, 2, 4)
     b.explicit_tiles = nullptr; b.n_explicit = 0;
     b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_scale = seg ? ctx->d_tk_scale : nullptr; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = ctx->tk_band_w;
+    if (block) { b.prune_band_lo = ctx->d_tk_band_lo; b.prune_band_hi = ctx->d_tk_band_hi; }
     // (measured at BA N = 100k: 2 phases overflow the lists -- the band thresholds meet half the columns at once --, 3 / 4 / 5 / 6 / 8 / 12 / 16 take
     //  66.3 / 65.7 / 65.6 / 66.8 / 68.8 / 72.1 / 74.5 ms with longest lists of 847 / 690 / 296 / 360 / 709 entries; twice the nodes, twice the appends per phase)
-    int n_phases = ctx->tk_nt <= 1200 ? 5 : 8;
+    int n_phases = npad / 128 <= 1200 ? 5 : 8;
     if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
     for (int ph = 0; ph < n_phases; ++ph) {
         b.phase = ph; b.phase_w = 1; b.n_phases = n_phases;
@@ -731,24 +813,26 @@ int topk_pruned(hsd_ctx *ctx, int k, int32_t *idx_out, double *dist_out, bool *d
         if (ph + 1 < n_phases && ((ph + 1) & ph) == 0)
             hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
     }
-    // select (the rows of real nodes are the first n positions), back to node order, out
+    // select (whole graph: the rows of real nodes are the first n positions; a block: its first bm), back to node order, out
     int flag[4] = {0, 0, 0, 0};
-    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap, (int64_t)0, n, k, d_oidx, d_oval,
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((out_rows + 3) / 4)), dim3(256), 0, ctx->stream, d_cnt, d_idx, d_val, (int)cap, (int64_t)0, out_rows, k, d_oidx, d_oval,
                        ctx->d_flag);
-    hipLaunchKernelGGL(tk_unpermute_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig, n, k, d_oidx, d_oval, d_fidx, d_fval);
+    // (row q of the result is node orig[p0 + q]; a block's nodes start at r0)
+    hipLaunchKernelGGL(tk_unpermute_kernel, dim3((unsigned)((out_rows * k + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_tk_orig + p0, out_rows, k, d_oidx, d_oval,
+                       d_fidx - (block ? r0 : 0) * k, d_fval - (block ? r0 : 0) * k);
     HSD_HIP(ctx, hipMemcpyAsync(flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     HSD_HIP(ctx, hipGetLastError());
     if (hsd_hook(H_TOPK_VERBOSE)) {
-        std::vector<int> hc((size_t)n);
-        (void)hipMemcpy(hc.data(), d_cnt, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+        std::vector<int> hc((size_t)out_rows);
+        (void)hipMemcpy(hc.data(), d_cnt, (size_t)out_rows * sizeof(int), hipMemcpyDeviceToHost);
         int64_t mx = 0;
         for (int v : hc) mx = std::max<int64_t>(mx, v);
-        fprintf(stderr, "[hsd topk] pruned sweep: capacity %lld, longest list %lld, overflow %d\n", (long long)cap, (long long)mx, flag[0] & 1);
+        fprintf(stderr, "[hsd topk] pruned sweep%s: capacity %lld, longest list %lld, overflow %d\n", block ? " (row block)" : "", (long long)cap, (long long)mx, flag[0] & 1);
     }
     if (flag[0] & 1) return HSD_OK;                 // a list overflowed (or came up short): the unpruned sweep takes the call
-    HSD_HIP(ctx, hipMemcpyAsync(idx_out, d_fidx, (size_t)n * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HSD_HIP(ctx, hipMemcpyAsync(dist_out, d_fval, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipMemcpyAsync(idx_out, d_fidx, (size_t)out_rows * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipMemcpyAsync(dist_out, d_fval, (size_t)out_rows * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *done = true;
     return HSD_OK;
@@ -777,10 +861,18 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
         //  12.4-13.0 and 20.9-21.5 ms and the default began at 100k nodes.)
         const bool l1 = ctx->mode == PAIR_L1_F64 && ctx->l1_cols_per_layer > 0 && ctx->dcols_alg > 0 && pr != 0;
         const bool zp = (ctx->mode == PAIR_SAD_U16 || ctx->mode == PAIR_SAD_U32) && ctx->n_seg >= 1 && (pr == 1 || (pr != 0 && ctx->npad / 128 >= 384));
-        if ((l1 || zp) && r0 == 0 && r1 == n && k <= 128 && !hsd_hook(H_TOPK_GEOM)) {
+        // (a row block -- a rank's share -- takes the pruned sweep too, whatever its bounds: its rows become positions of their own)
+        const bool whole = r0 == 0 && r1 == n, blk = !whole;
+        if ((l1 || zp) && (whole || blk) && k <= 128 && !hsd_hook(H_TOPK_GEOM)) {
             bool done = false;
-            const int rcp = topk_pruned(ctx, k, idx_out, dist_out, &done);
-            if (rcp != HSD_OK || done) return rcp;
+            const int rcp = topk_pruned(ctx, k, r0, r1, idx_out, dist_out, &done);
+            if (rcp == HSD_ERR_HIP || rcp == HSD_ERR_NOMEM || rcp == HSD_ERR_INTERNAL) {
+                // the pruned sweep needs a permuted copy of the operands, a sample matrix and rocprim's temporaries on top of what the unpruned
+                // sweep needs: when one of them cannot be had, the unpruned sweep -- which worked before the pruned one existed -- takes the call
+                hsd_tk_release(ctx);
+                (void)hipGetLastError();
+                if (hsd_hook(H_TOPK_VERBOSE)) fprintf(stderr, "[hsd topk] pruned sweep failed (%s): the unpruned sweep takes the call\n", hsd_last_error(ctx));
+            } else if (rcp != HSD_OK || done) return rcp;
         }
     }
 

@@ -14,6 +14,8 @@
 #include "common.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -195,5 +197,34 @@ int hsd_tk_order_device(hsd_ctx *ctx, const double *d_F, int64_t n64, int nf, in
     }
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     HSD_HIP(ctx, hipGetLastError());
+    return HSD_OK;
+}
+
+namespace {
+// position p of the order holds a node of the block [lo, hi)
+struct InBlock {
+    const int32_t *orig;
+    int32_t lo, hi;
+    __device__ bool operator()(const int32_t &p) const { const int32_t o = orig[p]; return o >= lo && o < hi; }
+};
+}  // namespace
+
+// The rows of a block [r0, r1) of nodes as a SUBSEQUENCE of the graph's node order: the positions whose node lies in the block, ascending (one
+// rocprim select over the positions; stable).  Consecutive block rows are then as similar as the order makes its neighbours, and 128 of them span a
+// contiguous run of the order's tiles -- which is what the pruned k-nearest sweep of a row block pairs them with first (pair_topk.hip).
+int hsd_tk_block_positions_device(hsd_ctx *ctx, const int32_t *d_orig, int64_t npos, int64_t r0, int64_t r1, int32_t *d_pos) {
+    if (npos < 1 || npos > 0x7fffff00ll || r0 < 0 || r1 <= r0) return hsd_fail(ctx, HSD_ERR_INVALID, "block positions: bad range");
+    Tmp dCount, dTmp;
+    HSD_HIP(ctx, dCount.alloc(sizeof(size_t)));
+    const InBlock pred{d_orig, (int32_t)r0, (int32_t)r1};
+    rocprim::counting_iterator<int32_t> first(0);
+    size_t bytes = 0;
+    HSD_HIP(ctx, rocprim::select(nullptr, bytes, first, d_pos, dCount.as<size_t>(), (size_t)npos, pred, ctx->stream));
+    HSD_HIP(ctx, dTmp.alloc(bytes));
+    HSD_HIP(ctx, rocprim::select(dTmp.p, bytes, first, d_pos, dCount.as<size_t>(), (size_t)npos, pred, ctx->stream));
+    size_t got = 0;
+    HSD_HIP(ctx, hipMemcpyAsync(&got, dCount.p, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+    HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((int64_t)got != r1 - r0) return hsd_fail(ctx, HSD_ERR_INTERNAL, "block positions: %zu of %lld nodes found in the order", got, (long long)(r1 - r0));
     return HSD_OK;
 }

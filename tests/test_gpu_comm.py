@@ -69,7 +69,7 @@ def test_two_ranks_run_the_hip_row_block_path(tmp_path, engine):
     """world = 2 through the code path of `bench.py --gpus 2`: hsd_comm_init(world = 2) (HSD_COMM_DRYRUN: no communicator,
     both ranks on this box's one GPU), per-rank sweeps, hsd_amd.distributed.allgather_signature(via="host"), then each rank's
     row block by the HIP kernels -- diagonal square + the rectangles on the side streams, persistent kernel forced -- and its
-    k-nearest rows.  The two blocks together are the one-GPU matrix, bit for bit for the Wasserstein variants."""
+    k-nearest rows by the pruned sweep of a row block.  The two blocks together are the one-GPU matrix, bit for bit for the Wasserstein variants."""
     import socket
     import subprocess
     import sys
@@ -82,11 +82,15 @@ def test_two_ranks_run_the_hip_row_block_path(tmp_path, engine):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSD_REPO=REPO, HSD_OUT=str(tmp_path), HSD_N=str(n), HSD_COMM_DRYRUN="1", HSD_STREAM="1",
+    # (HSD_TOPK_PRUNE=1: the k-nearest rows of a rank's block take the PRUNED sweep -- its rows as positions of their own behind the graph's order,
+    #  round 5 -- also for the zero-pad distance at this small size; the verbose log proves it ran)
+    env = dict(os.environ, HSD_REPO=REPO, HSD_OUT=str(tmp_path), HSD_N=str(n), HSD_COMM_DRYRUN="1", HSD_STREAM="1", HSD_TOPK_PRUNE="1", HSD_TOPK_VERBOSE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(w)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    log = p.stdout + p.stderr
+    assert log.count("pruned sweep (row block)") == 4 and log.count("overflow 0") >= 4 and "the unpruned sweep takes the call" not in log, log[-3000:]
     g = barabasi_albert(n, 4, 17)
     engine.set_graph(g.rowptr, g.col)
     engine.signature_build_degree(3)

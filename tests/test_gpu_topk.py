@@ -344,3 +344,72 @@ def test_pruned_sweep_of_the_zero_pad_distance_on_request(engine, capfd):
     kept = [tuple(int(x) for x in ln.split(":")[1].split("tile")[0].split("of")) for ln in log.splitlines() if "pruned launch" in ln]
     assert kept and sum(a for a, b in kept) < 0.9 * sum(b for a, b in kept) and "overflow 0" in log, log[-500:]
     assert np.array_equal(val, rval) and np.array_equal(idx, ridx)
+
+
+@pytest.mark.parametrize("mode,n,k,bounds", [
+    ((0, 0, 0, 3), 30000 + 77, 20, [(0, 3712), (3712, 7500), (11111, 20001), (26000, 30077)]),        # raw fp64: ragged bounds, first / middle / last block
+    ((0, 1, 0, 2), 30000 + 77, 20, [(0, 3840), (7680, 11500), (25001, 30077)]),                       # zero-pad (packed uint16 words)
+    ((0, 0, 0, 3), 20000, 1, [(2560, 5120)]),
+    ((0, 1, 0, 2), 20000, 128, [(17408, 20000)]),
+], ids=["raw-fp64", "zero-pad", "raw-k1", "zero-pad-k128"])
+def test_pruned_sweep_of_a_row_block(engine, capfd, mode, n, k, bounds):
+    """hsd_pair_topk(k, r0, r1) with r1 - r0 < n -- a rank's share of `--gpus P` -- takes the pruned sweep too: the block's rows are a second run of
+    positions behind the graph's k-d order (in that order), swept against ALL columns with row lists only.  Same lists as the unpruned call for
+    the block and as the rows of the whole-graph call, bit for bit, whatever the bounds; tile pairs are in fact dropped; a row never lists itself
+    although its own node is among the columns."""
+    from hsd_amd.graph import barabasi_albert
+    g = barabasi_albert(n, 5, 13)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(*mode)
+    with _env(HSD_TOPK_PRUNE=0):
+        widx, wval = engine.pair_topk(k)                     # the whole graph, unpruned: the reference
+    for r0, r1 in bounds:
+        with _env(HSD_TOPK_PRUNE=0):
+            uidx, uval = engine.pair_topk(k, r0, r1)
+        # (HSD_STREAM=1: a block of a few thousand rows of a 30k-node graph is below the size from which the persistent kernel -- the only one that
+        #  reads permuted operands -- is chosen by itself; a rank's block of config 4 is 25 000 x 200 000)
+        with _env(HSD_TOPK_PRUNE=1, HSD_TOPK_VERBOSE=1, HSD_STREAM=1):
+            capfd.readouterr()
+            idx, val = engine.pair_topk(k, r0, r1)
+            log = capfd.readouterr().err
+        assert "pruned sweep (row block)" in log and "overflow 0" in log and "the unpruned sweep takes the call" not in log, log[-800:]
+        kept = [tuple(int(x) for x in ln.split(":")[1].split("tile")[0].split("of")) for ln in log.splitlines() if "pruned launch" in ln]
+        print(f"rows [{r0}, {r1}): kept {sum(a for a, b in kept)} of {sum(b for a, b in kept)} tile pairs")
+        assert kept and sum(a for a, b in kept) < 0.97 * sum(b for a, b in kept), log[-600:]
+        assert idx.shape == (r1 - r0, k) and np.array_equal(val, uval) and np.array_equal(idx, uidx), (r0, r1)
+        assert np.array_equal(val, wval[r0:r1]) and np.array_equal(idx, widx[r0:r1])
+        assert not (idx == np.arange(r0, r1)[:, None]).any()
+        with _env(HSD_TOPK_PRUNE=1, HSD_STREAM=1):
+            idx2, val2 = engine.pair_topk(k, r0, r1)         # the block's setup is kept: the second call is the same call
+        assert np.array_equal(idx2, idx) and np.array_equal(val2, val)
+    with _env(HSD_TOPK_PRUNE=1):
+        idx, val = engine.pair_topk(k)                       # and back to the whole graph (another setup)
+    assert np.array_equal(idx, widx) and np.array_equal(val, wval)
+
+
+@pytest.mark.parametrize("n,k", [(300, 7), (1000, 16), (2222, 20)])
+def test_pruned_sweep_of_a_row_block_small_and_ragged(engine, n, k):
+    """Row blocks of the pruned sweep forced onto small graphs (HSD_STREAM=1, HSD_TOPK_PRUNE=1): blocks smaller than a tile, blocks that end inside
+    one, all-ties stars, both kinds and plain words -- against a lexicographic selection on the matrix rows."""
+    from hsd_amd.graph import Graph, barabasi_albert
+    if n == 1000:
+        half = n // 2
+        src = np.concatenate([[0], np.zeros(half - 1, dtype=np.int64), np.full(n - half - 1, half, dtype=np.int64)])
+        dst = np.concatenate([[half], np.arange(1, half), np.arange(half + 1, n)])
+        g = Graph.from_edges(list(range(n)), src, dst)
+    else:
+        g = barabasi_albert(n, 3, 5)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(2)
+    for mode, extra in (((0, 0, 0, 2), {}), ((0, 1, 0, 1), {}), ((0, 1, 0, 1), {"HSD_SAD16": 0})):
+        with _env(**extra):
+            engine.pair_prepare(*mode)
+            D = engine.pair_rows_host()
+        with _env(HSD_STREAM=1, HSD_TOPK_PRUNE=1, **extra):
+            engine.pair_prepare(*mode)
+            for r0, r1 in ((0, 50), (128, 256), (n // 3, n // 3 + 200), (n - 37, n), (1, n)):
+                r1 = min(r1, n)
+                ridx, rval = _reference_topk(D[r0:r1], k, r0)
+                idx, val = engine.pair_topk(k, r0, r1)
+                assert np.array_equal(val, rval) and np.array_equal(idx, ridx), (mode, extra, r0, r1)
