@@ -480,6 +480,8 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
             res["parity"] = parity_against(mat, p0, cpu[variant]["sample"])
         st = mat.stats()
         res["matrix_check"] = {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")}
+        if rk.world > 1 and metric == "wasserstein":
+            res["fused_knn"] = fused_knn_rank(eng, rk, mat, n, p0, p1, 20)
         if rk.world == 1 and metric == "wasserstein":
             res["fused_knn"] = fused_knn(eng, mat, n, 20)
             if n >= 50000:
@@ -543,6 +545,42 @@ def fused_knn(eng, mat, n, k):
     return dict(extra, call="hsd_pair_topk", k=k, ms_end_to_end=round(dt * 1e3, 3), ms_first_call=round(dt_first * 1e3, 3), rows_checked_against_matrix=3, exact=ok,
                 note="k nearest of every row without forming the matrix; time includes the results' copy to host memory (pruned sweep on node-permuted "
                      "operands where it applies: its one-time setup is in ms_first_call)")
+
+
+def fused_knn_rank(eng, rk, mat, n, r0, r1, k):
+    """The k-nearest consumer on P ranks: every rank asks for the k nearest of ITS rows, hsd_pair_topk(k, r0, r1) -- the pruned sweep of a row
+    block (the rank's rows as positions of their own behind the graph's node order; round 5) where it applies.  Timed end to end per rank (host
+    outputs), the slowest rank is the figure; rows checked against this rank's resident block of the matrix."""
+    if n <= k + 1 or r1 <= r0:
+        return None
+    try:
+        eng.sync()
+        rk.barrier()
+        t0 = time.perf_counter()
+        eng.pair_topk(k, r0, r1)                          # first call: scratch + the one-time setup of the pruned sweep
+        dt_first = time.perf_counter() - t0
+        rk.barrier()
+        t0 = time.perf_counter()
+        idx, val = eng.pair_topk(k, r0, r1)
+        dt = time.perf_counter() - t0
+        ok = True
+        for r in sorted({r0, (r0 + r1) // 2, r1 - 1}):
+            d = mat.rows_to_host(r - r0, r - r0 + 1)[0].copy()
+            d[r] = np.inf
+            order = np.lexsort((np.arange(n), d))[:k]
+            ok = ok and bool(np.array_equal(order, idx[r - r0]) and np.array_equal(d[order], val[r - r0]))
+        err = None
+    except Exception as e:                  # noqa: BLE001  (an extra figure: never fails the bench line; the ranks still meet below)
+        dt = dt_first = 0.0
+        ok, err = False, f"{type(e).__name__}: {e}"[:120]
+    per = rk.gather(dt * 1e3)
+    bad = rk.any(not ok)
+    out = dict(call="hsd_pair_topk(k, r0, r1) on every rank", k=k, ms_end_to_end=round(max(per), 3), ms_per_rank=[round(v, 3) for v in per],
+               ms_first_call=round(rk.max(dt_first * 1e3), 3), rows_checked_against_matrix=3 * rk.world, exact=not bad,
+               value=n * (n - 1) / 2.0 / (max(per) * 1e-3) if max(per) > 0 else None, unit="node-pairs/s")
+    if err:
+        out["error"] = err
+    return out
 
 
 def row_block_rehearsal(eng, mat, n, kernel_ms, heavy):

@@ -599,6 +599,17 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
             const int64_t q0 = (int64_t)t * 128, q1 = std::min<int64_t>(bm, q0 + 128) - 1;
             blo[(size_t)t] = std::max(0, block_pos[(size_t)q0] / 128 - band_w);
             bhi[(size_t)t] = std::min(nt_graph - 1, block_pos[(size_t)q1] / 128 + band_w);
+            // Where the block is thin in the graph's order its 128 rows span dozens of tiles, and every row of the tile would collect every column of
+            // that span that passes its sampled (2 % quantile) threshold: at most TK_BAND_MAX tiles -- 1 536 columns, below the lists' capacity
+            // of 2 048 whatever passes (seen without the cap at BA N = 200k, P = 8: 3 947 entries in the first launch, the list lost, the call
+            // repeated unpruned) -- around the tile of the middle row; the rest of the span comes with the phases like every other tile pair.
+            constexpr int TK_BAND_MAX = 12;
+            if (bhi[(size_t)t] - blo[(size_t)t] + 1 > TK_BAND_MAX) {
+                const int mid = block_pos[(size_t)((q0 + q1) / 2)] / 128;
+                const int lo = std::max(blo[(size_t)t], std::min(mid - TK_BAND_MAX / 2, bhi[(size_t)t] - TK_BAND_MAX + 1));
+                blo[(size_t)t] = lo;
+                bhi[(size_t)t] = lo + TK_BAND_MAX - 1;
+            }
             for (int c = blo[(size_t)t]; c <= bhi[(size_t)t]; ++c) band.push_back(make_int2(t, c));
         }
         if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_band_lo, (size_t)bt))) return rc;
@@ -723,7 +734,11 @@ int topk_pruned(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, d
     // rows of the sweep: positions [p0, p0 + rows); the per-row arrays below hold `rows` entries and are addressed by position (pointers moved
     // back by p0, as the unpruned sweep of a row block does with its node range)
     const int64_t p0 = block ? npad : 0, rows = block ? bpad : npad, out_rows = block ? bm : n;
-    const int64_t cap = std::max<int64_t>(2048, 512 + 8 * (int64_t)k);
+    // (a row block: rows whose own neighbourhood fell outside the capped first launch enter the first phase under their SAMPLED threshold -- the 2 %
+    //  quantile of 1 024 columns -- and meet n / phases columns there: the unpruned sweep's capacity rule, 4 130 entries at N = 200k; seen with
+    //  2 048: one row of rank 7 of 8 appended 2 091 in the first phase, lost its list and the call was repeated unpruned)
+    const int64_t phases_dflt = npad / 128 <= 1200 ? 5 : 8;
+    const int64_t cap = std::max<int64_t>(std::max<int64_t>(2048, 512 + 8 * (int64_t)k), block ? 8 * (int64_t)k * n / (1024 * phases_dflt) + 8 * k + 64 : 0);
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t oTau = carve((size_t)rows * sizeof(double)), oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
@@ -798,6 +813,20 @@ int topk_pruned(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, d
     b.explicit_tiles = reinterpret_cast<const int2 *>(ctx->d_tk_band); b.n_explicit = ctx->tk_band_n;
     if (block) { b.prune_lo = ctx->d_tk_lo; b.prune_hi = ctx->d_tk_hi; b.prune_scale = seg ? ctx->d_tk_scale : nullptr; b.prune_nf = ctx->tk_nf; b.prune_nt = ctx->tk_nt; b.prune_drop_band = 0; }
     if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
+    const bool verbose = hsd_hook(H_TOPK_VERBOSE) != nullptr;
+    const auto list_stats = [&](const char *when) {
+        // HSD_TOPK_VERBOSE: the lists after a launch -- longest, shortest, rows still below k entries (their thresholds cannot tighten)
+        if (!verbose) return;
+        std::vector<int> hc((size_t)out_rows);
+        std::vector<double> ht((size_t)out_rows);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(hc.data(), d_cnt, (size_t)out_rows * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ht.data(), d_tau, (size_t)out_rows * sizeof(double), hipMemcpyDeviceToHost);
+        int64_t mx = 0, at = 0, below = 0;
+        for (int64_t q = 0; q < out_rows; ++q) { if (hc[(size_t)q] > mx) { mx = hc[(size_t)q]; at = q; } below += hc[(size_t)q] < k; }
+        fprintf(stderr, "[hsd topk] %s: longest list %lld (row position %lld, threshold %.6g), %lld rows below k entries\n", when, (long long)mx, (long long)at, ht[(size_t)at], (long long)below);
+    };
+    list_stats("first launch");
     hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
     // the rest of the pair space in anti-diagonal phases, each filtered against the thresholds of the moment (tightened after phases 1, 2, 4)
     b.explicit_tiles = nullptr; b.n_explicit = 0;
@@ -805,11 +834,12 @@ int topk_pruned(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, d
     if (block) { b.prune_band_lo = ctx->d_tk_band_lo; b.prune_band_hi = ctx->d_tk_band_hi; }
     // (measured at BA N = 100k: 2 phases overflow the lists -- the band thresholds meet half the columns at once --, 3 / 4 / 5 / 6 / 8 / 12 / 16 take
     //  66.3 / 65.7 / 65.6 / 66.8 / 68.8 / 72.1 / 74.5 ms with longest lists of 847 / 690 / 296 / 360 / 709 entries; twice the nodes, twice the appends per phase)
-    int n_phases = npad / 128 <= 1200 ? 5 : 8;
+    int n_phases = (int)phases_dflt;
     if (const char *ep = hsd_hook(H_TOPK_PHASES)) n_phases = std::max(1, std::min(16, atoi(ep)));
     for (int ph = 0; ph < n_phases; ++ph) {
         b.phase = ph; b.phase_w = 1; b.n_phases = n_phases;
         if ((rc = launch_region(ctx, b, BT, ctx->stream))) return rc;
+        list_stats("phase");
         if (ph + 1 < n_phases && ((ph + 1) & ph) == 0)
             hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), cmp_lds, ctx->stream, d_cnt, d_idx, d_val, (int)cap, rows, k, 0.0, d_tau);
     }
