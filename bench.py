@@ -1041,7 +1041,18 @@ def main():
         # control plane only (unique-id broadcast, barriers, max over ranks); the data-plane
         # exchange is the library's own ncclAllGather over RCCL
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (gloo's C++ side reports "[Gloo] Rank r is connected to ..." on STDOUT: while the group forms, file descriptor 1 points at stderr, so that
+        #  stdout stays what the contract says -- the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     rk = Ranks(dist, rank, world)
 
     # HSD_COMM_DRYRUN=1 rehearses the multi-rank flow on a box with fewer GPUs than ranks: every rank on GPU 0,
