@@ -50,9 +50,9 @@ const HsdHookInfo hsd_hook_table[H_COUNT] = {
     {"HSD_U8", "0 = packed zero-pad layers without their uint8 ranges; read at prepare time"},
     {"HSD_SHARD_BALANCE", "0 = hsd_pair_shard returns blocks of equal height whatever the kind"},
     {"HSD_KL_POINT", "KL kinds: 0 = layer 0 (ring 0 = the node itself) stays in the dense loop instead of its closed form; read at prepare time"},
-    {"HSD_DEBUG", "ablation bits of the pair kernels: 1 no stores, 2 no arithmetic, 16 stores stay in L2; 4 / 8 only in -DHSD_STAMPS builds"},
+    {"HSD_DEBUG", "(-DHSD_DEBUG_HOOKS builds only: `make debug`) ablation bits of the pair kernels: 1 no stores, 2 no arithmetic, 16 stores stay in L2; 4 / 8 only in -DHSD_STAMPS builds"},
     {"HSD_SIDE_STREAMS", "0 = the three regions of a row block in sequence instead of side by side (three-launch form only)"},
-    {"HSD_TOPK_DEBUG", "fused k-nearest consumer: 1 = sweep without its candidate epilogue (timing only: the call then fails); 32 = pruned sweep without the early exit of finished waves (A/B)"},
+    {"HSD_TOPK_DEBUG", "(-DHSD_DEBUG_HOOKS builds only) fused k-nearest consumer: 1 = sweep without its candidate epilogue (timing only: the call then fails); 32 = pruned sweep without the early exit of finished waves (A/B)"},
     {"HSD_TOPK_PRUNE", "fused k-nearest consumer over the whole graph: 0 = never the pruned sweep on node-permuted operands; 1 = whenever the kind allows (default: the raw fp64 distance where the persistent kernel runs, the zero-pad distance from ~50k nodes on)"},
     {"HSD_TOPK_GROUPS", "pruned k-nearest sweep: column groups per layer in the lower bound (1..8, default 1); read when the permuted operands are built"},
     {"HSD_TOPK_BAND", "pruned k-nearest sweep: the first launch evaluates every tile against itself and this many successors in the node order (1..4, default 1); read when the permuted operands are built"},

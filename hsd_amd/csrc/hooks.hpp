@@ -2,6 +2,7 @@
 // tests/test_abi.py).  They exist for measurements (A/B of kernel forms inside one process) and tests (forcing a path a size
 // heuristic would not pick, rehearsing a failure); none changes results beyond rounding order.  A deployment that wants no
 // environment-dependent behaviour builds with -DHSD_NO_ENV_HOOKS: hsd_hook() is then a constant nullptr and every default holds.
+// The two ablation hooks (HSD_DEBUG, HSD_TOPK_DEBUG: wrong results on purpose) exist only in a -DHSD_DEBUG_HOOKS build.
 // HSD_HOOKS_LIST=1 prints the table (name, current value, meaning) to stderr when a context is created.
 #pragma once
 
@@ -55,9 +56,19 @@ enum HsdHook {
 struct HsdHookInfo { const char *name, *doc; };
 extern const HsdHookInfo hsd_hook_table[H_COUNT];
 
+// Hooks that make a call return WRONG results or fail on purpose (ablations for timing: kernels without their stores, without their arithmetic,
+// a sweep without its candidate epilogue) are read only by a measurement build (-DHSD_DEBUG_HOOKS: `make debug` -> libhsd_amd_dbg.so, loaded
+// through HSD_LIB by the A/B tools of tools_dev/); the shipped library ignores them, whatever the environment says.
+constexpr bool hsd_hook_is_ablation(HsdHook h) { return h == H_DEBUG || h == H_TOPK_DEBUG; }
+
 #ifdef HSD_NO_ENV_HOOKS
 inline const char *hsd_hook(HsdHook) { return nullptr; }
 #else
-inline const char *hsd_hook(HsdHook h) { return getenv(hsd_hook_table[h].name); }
+inline const char *hsd_hook(HsdHook h) {
+#ifndef HSD_DEBUG_HOOKS
+    if (hsd_hook_is_ablation(h)) return nullptr;
+#endif
+    return getenv(hsd_hook_table[h].name);
+}
 #endif
 inline int hsd_hook_int(HsdHook h, int dflt) { const char *e = hsd_hook(h); return e ? atoi(e) : dflt; }

@@ -80,6 +80,17 @@ def test_environment_hooks_are_one_table_and_documented():
             assert not stray, (f, stray)
 
 
+def test_ablation_hooks_are_not_in_the_shipped_build():
+    """HSD_DEBUG / HSD_TOPK_DEBUG make a call return wrong results or fail on purpose (timing ablations): only a -DHSD_DEBUG_HOOKS build (`make debug`,
+    loaded through HSD_LIB) reads them; the default build's flags do not define it (tests/test_gpu_tools.py checks the behaviour on the GPU)."""
+    csrc = os.path.join(REPO, "hsd_amd", "csrc")
+    hooks = open(os.path.join(csrc, "hooks.hpp"), encoding="utf-8").read()
+    assert "hsd_hook_is_ablation" in hooks and "#ifndef HSD_DEBUG_HOOKS" in hooks and "h == H_DEBUG || h == H_TOPK_DEBUG" in hooks
+    mk = open(os.path.join(csrc, "Makefile"), encoding="utf-8").read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith("CXXFLAGS")]
+    assert len(flags) == 1 and "HSD_DEBUG_HOOKS" not in flags[0] and "debug:" in mk and "-DHSD_DEBUG_HOOKS" in mk
+
+
 def test_no_oracle_import_in_product():
     """The product path must never route through the CPU oracle."""
     pkg = os.path.join(REPO, "hsd_amd")

@@ -64,6 +64,28 @@ def test_two_models_share_one_engine(engine):
     assert m1.get_nodes_hierarchical_degree()[m1.nodes[0]][0] == 1
 
 
+def test_ablation_hooks_are_ignored_by_the_shipped_library(engine):
+    """HSD_DEBUG=1 (the pair kernels without their stores) and HSD_TOPK_DEBUG=1 (the sweep without its candidate epilogue: "the call then fails") are
+    measurement switches of `make debug` builds; the library the package ships must not look at them."""
+    from hsd_amd.graph import barabasi_albert
+    g = barabasi_albert(3000, 4, 3)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 1, 0, 2)
+    os.environ["HSD_STREAM"] = "1"
+    try:
+        D = engine.pair_rows_host()
+        idx, val = engine.pair_topk(5)
+        os.environ["HSD_DEBUG"] = "3"
+        os.environ["HSD_TOPK_DEBUG"] = "1"
+        D2 = engine.pair_rows_host()
+        idx2, val2 = engine.pair_topk(5)
+    finally:
+        for k in ("HSD_STREAM", "HSD_DEBUG", "HSD_TOPK_DEBUG"):
+            os.environ.pop(k, None)
+    assert D.max() > 0 and np.array_equal(D, D2) and np.array_equal(idx, idx2) and np.array_equal(val, val2)
+
+
 def _check_contract_line(stdout, n_gpus, steps, warmup):
     """stdout of bench.py is the contract line and nothing else: compact (the driver reads a tail of stdout -- round 4's 20 KB line was lost), strict
     JSON, the contract's keys with the roofline / cpu_baseline / parity objects, value consistent with ms_per_step; the detail record holds the rest."""
