@@ -273,7 +273,7 @@ def time_pair(eng, mat, r0, r1, steps, warmup, barrier):
 def load_traffic(key):
     """HBM bytes per launch from the PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected in
     their own runs as MI355X_MICROARCH.md prescribes; summaries under profiles/).  None if that workload was not profiled."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 t = json.load(f).get(key)

@@ -92,6 +92,13 @@ struct hsd_ctx {
     std::vector<double> support;
     bool support_integral = false;
 
+    // Operand arena (csrc/context.hip, hsd_pool_*): the prepared operand sets, the k-nearest sweep's permuted copies and hsd_pair_prepare's
+    // temporaries come out of a GROW-ONLY pool of device blocks -- a released block stays allocated and serves the next request of about its
+    // size.  Before round 5 every hsd_pair_prepare freed and re-allocated ~1 GB (hipFree synchronises the device; the first calls behind such a
+    // re-allocation came out 20-25 ms late once in ~25 times): a caller that prepares one distance per scale paid that.
+    struct PoolBlock { void *p; size_t bytes; bool used; };
+    std::vector<PoolBlock> op_pool;
+
     // prepared pair operands
     int mode = PAIR_NONE;
     int64_t npad = 0;                  // node stride of the bin-major matrices (multiple of HSD_TILE)
@@ -235,6 +242,23 @@ static inline int hsd_dev_alloc(hsd_ctx *ctx, T **p, size_t count) {
 template <typename T>
 static inline void hsd_dev_free(T *&p) {
     if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// operand arena (see hsd_ctx::op_pool): a block of at least `bytes`; hsd_pool_free keeps the block for the next request (the caller has synchronised
+// the context's stream -- nothing in flight reads it -- as it had to before a hipFree of the same block could return); a pointer that did not come
+// from the pool is handed to hipFree.  hsd_pool_trim releases the unused blocks (all = true: every block; hsd_destroy).
+int hsd_pool_alloc(hsd_ctx *ctx, void **p, size_t bytes);
+void hsd_pool_free(hsd_ctx *ctx, void *p);
+void hsd_pool_trim(hsd_ctx *ctx, bool all);
+
+template <typename T>
+static inline int hsd_op_alloc(hsd_ctx *ctx, T **p, size_t count) {
+    return hsd_pool_alloc(ctx, reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T));
+}
+template <typename T>
+static inline void hsd_op_free(hsd_ctx *ctx, T *&p) {
+    if (p) hsd_pool_free(ctx, p);
     p = nullptr;
 }
 
