@@ -83,6 +83,8 @@ def parse():
                          "'none' to skip.  Default: extra,2,3,4,5 at --gpus 1, 4 at --gpus 8, none otherwise")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the scipy baseline sample of the headline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip what rides beside the timed steps (k-nearest consumer, row-block rehearsal): a profile of this "
+                    "run then holds the matrix launches of the all-pairs kernels and nothing else of the same instantiation (tools_dev/prof.sh)")
     ap.add_argument("--detail", default=None, help="file name of the detail record (default bench_detail.json, next to bench.py and under gpurun_out/)")
     ap.add_argument("--weak", action="store_true", help="round-1 weak-scaling mode: ER N = nodes * sqrt(P), per-GPU output fixed")
     # overrides (measurement scripts): a custom graph instead of a named workload
@@ -376,6 +378,9 @@ class Ranks:
         return bool(self.max(1.0 if flag else 0.0))
 
 
+EXTRAS = True           # --no-extras clears it
+
+
 def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, traffic_prefix=None, dryrun=False):
     """k-hop sweep + histograms (this rank's sources), the exchange, then every variant: prepare, first call, timed
     steps.  Returns dict(variants={name: result}, phases, sweep, n_bins)."""
@@ -480,9 +485,9 @@ def run_degree_workload(eng, rk, g, spec, variants, steps, warmup, cpu=None, tra
             res["parity"] = parity_against(mat, p0, cpu[variant]["sample"])
         st = mat.stats()
         res["matrix_check"] = {k: st[k] for k in ("sum", "max_abs_diag", "max_asym")}
-        if rk.world > 1 and metric == "wasserstein":
+        if rk.world > 1 and metric == "wasserstein" and EXTRAS:
             res["fused_knn"] = fused_knn_rank(eng, rk, mat, n, p0, p1, 20)
-        if rk.world == 1 and metric == "wasserstein":
+        if rk.world == 1 and metric == "wasserstein" and EXTRAS:
             res["fused_knn"] = fused_knn(eng, mat, n, 20)
             if n >= 50000:
                 res["row_block_rehearsal"] = row_block_rehearsal(eng, mat, n, res["roofline"]["kernel_ms"], heavy=(variant == "A"))
@@ -987,6 +992,8 @@ def emit(detail, detail_name=None):
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    global EXTRAS
+    EXTRAS = not args.no_extras
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

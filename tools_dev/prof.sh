@@ -2,14 +2,14 @@
 # usage (GPU box): tools_dev/prof.sh <tag> <bench args...>
 # rocprofv3 kernel-trace stats of `python3 bench.py <args>` + separate PMC passes (never combined
 # with trace domains). Writes gpurun_out/prof_<tag>/summary.txt (+ the raw CSVs).
-# PROF_STEPS / PROF_WARMUP (default 5 / 1) set the launches per pass; PROF_PASSES="trace pmc1 pmc2 pmc3 pmc4 pmc5" selects passes.
+# PROF_STEPS / PROF_WARMUP (default 5 / 1) set the launches per pass; PROF_EXTRA_ARGS (default --no-extras: only the matrix launches of the all-pairs kernels); PROF_PASSES="trace pmc1 pmc2 pmc3 pmc4 pmc5" selects passes.
 set -o pipefail
 tag=$1; shift
 R=$PWD
 out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-BENCH_ARGS="--cpu-seconds 0 --steps ${PROF_STEPS:-5} --warmup ${PROF_WARMUP:-1} $*"
+BENCH_ARGS="--cpu-seconds 0 --steps ${PROF_STEPS:-5} --warmup ${PROF_WARMUP:-1} ${PROF_EXTRA_ARGS---no-extras} $*"
 PASSES=${PROF_PASSES:-trace pmc1 pmc2 pmc3 pmc4 pmc5}
 run() { name=$1; shift; case " $PASSES " in *" $name "*) ;; *) return 0;; esac
         (cd /tmp && rocprofv3 "$@" -d $out/$name --output-format csv -- python3 $R/bench.py $BENCH_ARGS > $out/$name.log 2>&1) || { tail -5 $out/$name.log; return 1; }

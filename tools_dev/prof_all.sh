@@ -6,14 +6,14 @@ tag=${1:-rXX}
 ticker=$!
 trap 'kill $ticker 2>/dev/null' EXIT
 set -x
-PROF_PASSES="trace" tools_dev/prof.sh ${tag}_bench_default > gpurun_out/prof_${tag}_bench_default.log 2>&1 || exit 1
+PROF_PASSES="trace" PROF_EXTRA_ARGS="" tools_dev/prof.sh ${tag}_bench_default > gpurun_out/prof_${tag}_bench_default.log 2>&1 || exit 1
 PROF_STEPS=3 tools_dev/prof.sh ${tag}_target --configs none > gpurun_out/prof_${tag}_target.log 2>&1 || exit 1
 PROF_STEPS=3 tools_dev/prof.sh ${tag}_config3 --workload config3 > gpurun_out/prof_${tag}_config3.log 2>&1 || exit 1
 PROF_STEPS=20 tools_dev/prof.sh ${tag}_config2 --workload config2 > gpurun_out/prof_${tag}_config2.log 2>&1 || exit 1
 # config 5: the Chebyshev kernels of MultiHSD at FULL size (BA N = 50 000) under the counters, ONE impulse block (rows [0, 1024):
 # 50 cheby_step dispatches -- all 4 000 of the whole pass outlast a gpurun call under PMC); the kernel-trace of the whole
 # run is in ${tag}_bench_default
-[ -n "$SKIP_CFG5" ] && exit 0        # (its kernels did not change since the last collection)
+[ -n "$SKIP_CFG5" ] && exit 0        # (only when its kernels did not change since the last collection -- and then say so in the copied file)
 export TMPDIR=/tmp
 R=$PWD; out=$R/gpurun_out/prof_${tag}_config5_block; rm -rf $out; mkdir -p $out
 for pass in "pmc4 FETCH_SIZE" "pmc5 WRITE_SIZE" "pmc3 GRBM_GUI_ACTIVE"; do
