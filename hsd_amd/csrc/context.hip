@@ -61,6 +61,7 @@ const HsdHookInfo hsd_hook_table[H_COUNT] = {
     {"HSD_TOPK_GEOM", "fused k-nearest consumer: 0 | 1 = never / always the geometric launch schedule"},
     {"HSD_TOPK_CAP", "fused k-nearest consumer: capacity of a row's candidate list (overflow -> retry path)"},
     {"HSD_TOPK_VERBOSE", "fused k-nearest consumer: per-attempt list statistics to stderr"},
+    {"HSD_TOPK_NOMEM", "test hook: rehearses a failed device allocation inside the pruned sweep's setup (the unpruned sweep must take the call)"},
 };
 
 int hsd_guard_status(hsd_ctx *ctx, int status, const char *what) noexcept {

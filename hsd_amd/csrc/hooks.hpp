@@ -50,6 +50,7 @@ enum HsdHook {
     H_TOPK_GEOM,
     H_TOPK_CAP,
     H_TOPK_VERBOSE,
+    H_TOPK_NOMEM,
     H_COUNT
 };
 

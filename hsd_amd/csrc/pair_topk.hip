@@ -619,6 +619,7 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
     }
     ctx->tk_band_w = band_w;
     mark("tile intervals + first-launch list");
+    if (hsd_hook(H_TOPK_NOMEM)) return hsd_fail(ctx, HSD_ERR_HIP, "hipMalloc: out of memory (HSD_TOPK_NOMEM rehearsal)");
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npos))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
     if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;

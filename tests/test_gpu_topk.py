@@ -413,3 +413,31 @@ def test_pruned_sweep_of_a_row_block_small_and_ragged(engine, n, k):
                 ridx, rval = _reference_topk(D[r0:r1], k, r0)
                 idx, val = engine.pair_topk(k, r0, r1)
                 assert np.array_equal(val, rval) and np.array_equal(idx, ridx), (mode, extra, r0, r1)
+
+
+def test_pruned_sweep_hands_over_when_its_setup_cannot_allocate(engine, capfd):
+    """The pruned sweep needs a permuted copy of the operands, a sample matrix and rocprim temporaries on top of what the unpruned sweep needs.  When one of
+    those cannot be had (HSD_TOPK_NOMEM rehearses the failed allocation half-way through the setup) the call must not fail: the setup is released and the
+    unpruned sweep -- which worked before the pruned one existed -- returns the same lists; the next call sets up again."""
+    from hsd_amd.graph import barabasi_albert
+    n, k = 20000 + 5, 12
+    g = barabasi_albert(n, 5, 3)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    engine.pair_prepare(0, 0, 0, 3)
+    with _env(HSD_TOPK_PRUNE=0):
+        ridx, rval = engine.pair_topk(k)
+        bidx, bval = engine.pair_topk(k, 4096, 9000)
+    for rows, want in (((0, None), (ridx, rval)), ((4096, 9000), (bidx, bval))):
+        with _env(HSD_TOPK_NOMEM=1, HSD_TOPK_VERBOSE=1, HSD_STREAM=1):
+            capfd.readouterr()
+            idx, val = engine.pair_topk(k, *rows)
+            log = capfd.readouterr().err
+        assert "the unpruned sweep takes the call" in log and "HSD_TOPK_NOMEM" in log, log[-600:]
+        assert np.array_equal(idx, want[0]) and np.array_equal(val, want[1])
+        with _env(HSD_TOPK_VERBOSE=1, HSD_STREAM=1):
+            capfd.readouterr()
+            idx, val = engine.pair_topk(k, *rows)                  # no failure this time: the pruned sweep sets up and runs
+            log = capfd.readouterr().err
+        assert "pruned launch" in log and "overflow 0" in log and "the unpruned sweep takes the call" not in log
+        assert np.array_equal(idx, want[0]) and np.array_equal(val, want[1])

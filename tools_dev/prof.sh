@@ -9,7 +9,7 @@ R=$PWD
 out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-BENCH_ARGS="--cpu-seconds 0 --steps ${PROF_STEPS:-5} --warmup ${PROF_WARMUP:-1} ${PROF_EXTRA_ARGS---no-extras} $*"
+BENCH_ARGS="--cpu-seconds 0 --steps ${PROF_STEPS:-5} --warmup ${PROF_WARMUP:-1} ${PROF_EXTRA_ARGS---no-extras} --detail prof_detail.json $*"
 PASSES=${PROF_PASSES:-trace pmc1 pmc2 pmc3 pmc4 pmc5}
 run() { name=$1; shift; case " $PASSES " in *" $name "*) ;; *) return 0;; esac
         (cd /tmp && rocprofv3 "$@" -d $out/$name --output-format csv -- python3 $R/bench.py $BENCH_ARGS > $out/$name.log 2>&1) || { tail -5 $out/$name.log; return 1; }
