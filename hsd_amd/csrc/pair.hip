@@ -127,6 +127,34 @@ __device__ inline void gstore16_s(uint64_t sbase, uint32_t lane_off, v2f64 val) 
 
 // Stage CH columns x BT nodes of one operand: LDS image [CH][BT] of T (linear, as in memory).
 // FAST: direct-to-LDS loads (needs 16-B aligned column slices); else through registers.
+// One store of a deferred group at a site of its trip (HSD_STORE_SPREAD, pair_stream_kernel): group g < 4 stores tuple d[g], group 4 + k tuple m[k],
+// g >= 8 nothing -- chosen by scalar compares and branches INSIDE the statement, so that the compiler sees no control flow in the straight-line trip.
+__device__ __attribute__((always_inline)) inline void spread_store_asm(int g, uint32_t v, uint64_t sb, v2f64 d0, v2f64 d1, v2f64 d2, v2f64 d3, v2f64 m0, v2f64 m1,
+                                                                       v2f64 m2, v2f64 m3) {
+        asm volatile(
+            "s_cmp_gt_u32 %[g], 7\n\ts_cbranch_scc1 9f\n\t"
+            "s_cmp_gt_u32 %[g], 3\n\ts_cbranch_scc1 4f\n\t"
+            "s_cmp_eq_u32 %[g], 0\n\ts_cbranch_scc1 0f\n\t"
+            "s_cmp_eq_u32 %[g], 1\n\ts_cbranch_scc1 1f\n\t"
+            "s_cmp_eq_u32 %[g], 2\n\ts_cbranch_scc1 2f\n\t"
+            "global_store_dwordx4 %[v], %[d3], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "0:\n\tglobal_store_dwordx4 %[v], %[d0], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "1:\n\tglobal_store_dwordx4 %[v], %[d1], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "2:\n\tglobal_store_dwordx4 %[v], %[d2], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "4:\n\ts_cmp_eq_u32 %[g], 4\n\ts_cbranch_scc1 5f\n\t"
+            "s_cmp_eq_u32 %[g], 5\n\ts_cbranch_scc1 6f\n\t"
+            "s_cmp_eq_u32 %[g], 6\n\ts_cbranch_scc1 7f\n\t"
+            "global_store_dwordx4 %[v], %[m3], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "5:\n\tglobal_store_dwordx4 %[v], %[m0], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "6:\n\tglobal_store_dwordx4 %[v], %[m1], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n\ts_branch 9f\n"
+            "7:\n\tglobal_store_dwordx4 %[v], %[m2], %[sb] " HSD_STORE_BITS "\n\ts_nop 1\n"
+            "9:\n\ts_nop 0"
+            :
+            : [g] "s"(g), [v] "v"(v), [sb] "s"(sb),
+              [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3)
+            : "memory", "scc");
+}
+
 template <typename T, bool FAST, int BT, int CH>
 __device__ inline void stage_side(const T *__restrict__ Xg, int64_t npad, int c0, int64_t n0, T *__restrict__ dst, int tid) {
     if constexpr (FAST) {
@@ -997,6 +1025,51 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         return 8;
     };
 
+#if HSD_STORE_SPREAD
+    // EXPERIMENT (round 5): the eight stores of a deferred group leave one behind each WORD of the group's 8-word trip (64 SADs, ~260 cycles, apart)
+    // instead of back to back in front of it: a store holds its wave only against the next vector-memory instruction, so spaced like this none
+    // waits, and the SIMD's other wave never runs alone.  Rounds 3 and 4 wrote this in C++ three times: the eight-way choice of the accumulator
+    // tuple at each site is control flow inside the straight-line trip, and hipcc answered with 464 / 800 / 1 300 spilled registers.  Here the
+    // choice is made INSIDE one asm statement per site (scalar compares and branches around eight store instructions): the compiler sees a
+    // statement that reads eight tuples which are live anyway, a scalar base and one lane offset.
+    // (trip-local state, so that every value is a straight-line result of v_readfirstlane and lives in scalar registers: sp_g the group this trip
+    //  carries (8: none), sp_sb its row granule's base, sp_v the lane part of the offsets -- direct: row 2 ly, bytes 16 lx; mirrored: row 2 lx, bytes
+    //  16 ly --, sp_G the byte offsets of the four granules of the OTHER side within a matrix row)
+    // a wave-uniform value into a scalar register for good (an asm result of class "s": whatever the compiler thought of the value's uniformity)
+    auto to_s = [](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+        uint32_t r;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane(x)));
+        return r;
+    };
+    auto spread_begin = [&](int &sp_g, uint64_t &sp_sb, uint32_t &sp_v, uint32_t (&sp_G)[4]) __attribute__((always_inline)) {
+        if (pend_g == 4 && pend_mirror) transpose_acc();
+        if (pend_g >= 4 && !pend_mirror) pend_g = 8;
+        const int g = pend_g < 8 ? pend_g : 8;        // (8: nothing pending -- the sites then store nothing; the values below are formed all the same)
+        // (the tile's granules straight out of the plan ring, at computed positions: two small arrays chosen between by `mir` became a scratch array
+        //  under a dynamic index -- three scratch loads with vmcnt(0) at the top of every trip)
+        const bool mir = g >= 4;
+        const int gg = g & 3;
+        const int own = pend_ms * META + (mir ? 8 + 4 * (w & 1) : 4 * (w >> 1)), other = pend_ms * META + (mir ? 4 * (w >> 1) : 8 + 4 * (w & 1));
+        const int rowg = __builtin_amdgcn_readfirstlane(meta[own + gg]);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) sp_G[qq] = to_s((uint32_t)(128 * meta[other + qq]));
+        sp_sb = (uint64_t)uniform64(reinterpret_cast<int64_t>(a.out + ((int64_t)16 * rowg - a.rbase) * a.ld));
+        asm volatile("s_nop 4" : "+s"(sp_sb));         // vector-ALU-written scalar -> address: five wait states
+        const int lv = lane(), lyv = lane_y(lv), lxv = lane_x(lv);
+        const uint32_t ld8 = (uint32_t)a.ld * 8u;
+        sp_v = mir ? (uint32_t)(2 * lxv) * ld8 + (uint32_t)(16 * lyv) : (uint32_t)(2 * lyv) * ld8 + (uint32_t)(16 * lxv);
+        sp_g = (int)to_s((uint32_t)g);
+    };
+    // site s = 4 par + q of the trip: direct group k stores tuple [2 k + par][q], mirrored group 4 + k tuple [2 q + par][k]
+    auto spread_site = [&](auto S_, int sp_g, uint64_t sp_sb, uint32_t sp_v, const uint32_t (&sp_G)[4]) __attribute__((always_inline)) {
+        constexpr int S = decltype(S_)::value, par = S >> 2, q = S & 3;
+        uint64_t sbs = sp_sb + (uint64_t)((par ? (uint32_t)a.ld * 8u : 0u) + sp_G[q]);
+        asm volatile("" : "+s"(sbs));                  // (scalar adds of scalar registers: no hazard towards the address use)
+        spread_store_asm(sp_g, sp_v, sbs, acc2[0 + par][q], acc2[2 + par][q], acc2[4 + par][q], acc2[6 + par][q], acc2[2 * q + par][0], acc2[2 * q + par][1],
+                         acc2[2 * q + par][2], acc2[2 * q + par][3]);
+    };
+#endif
+
     // a layer's integer sums: zero here, and every fold leaves them at zero again (every layer closes with a fold)
     T part[TR][TC];
     if constexpr (SEG) {
@@ -1157,6 +1230,34 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             load_ops(c, 0);
 #pragma unroll 1
             for (; UNR > 2 && c + UNR <= cend; c += UNR) {          // straight-line body: counted LDS waits (see pair_kernel)
+#if HSD_STORE_SPREAD
+                int sp_g = 8;
+                uint64_t sp_sb = 0;
+                uint32_t sp_v = 0, sp_G[4] = {0u, 0u, 0u, 0u};
+                if constexpr (DEFERS && UNR == 8) spread_begin(sp_g, sp_sb, sp_v, sp_G);
+                auto two_words = [&](auto U_) __attribute__((always_inline)) {
+                    constexpr int u = decltype(U_)::value;
+                    load_ops(c + u + 1, 1);
+                    HSD_PIN_ORDER;
+                    compute(0, BYTES);
+                    HSD_PIN_ORDER;
+                    if constexpr (DEFERS && UNR == 8) spread_site(std::integral_constant<int, u>{}, sp_g, sp_sb, sp_v, sp_G);
+                    load_ops(c + u + 2, 0);
+                    HSD_PIN_ORDER;
+                    compute(1, BYTES);
+                    HSD_PIN_ORDER;
+                    if constexpr (DEFERS && UNR == 8) spread_site(std::integral_constant<int, u + 1>{}, sp_g, sp_sb, sp_v, sp_G);
+                };
+                two_words(std::integral_constant<int, 0>{});
+                two_words(std::integral_constant<int, 2>{});
+                if constexpr (UNR >= 8) {
+                    two_words(std::integral_constant<int, 4>{});
+                    two_words(std::integral_constant<int, 6>{});
+                }
+                if constexpr (DEFERS && UNR == 8) {
+                    if (sp_g < 8) { vm_seq += 8; pend_g = sp_g + 1; }
+                }
+#else
                 if constexpr (DEFERS) {
                     // one group of the previous tile's results in front of every 8-word trip (~2 100 cycles of arithmetic apart:
                     // the store path never sees a burst; two bursts of 32 in front of the first two chunks: +0.25 of 16.7 ms)
@@ -1179,6 +1280,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                     compute(1, BYTES);
                     HSD_PIN_ORDER;
                 }
+#endif
             }
             if constexpr (DEFERS) {
                 // ... and one in front of the shorter rest of a sweep (four words or more)

@@ -21,6 +21,9 @@ namespace hsd_pair {
 #ifndef HSD_STAMPS
 #define HSD_STAMPS 0                // 1: the persistent kernel carries its in-kernel cycle stamps (HSD_DEBUG bit 3) and the plain-store switch
 #endif                              //    (bit 2) -- a measurement build: a dozen scalar registers the product kernel needs for itself
+#ifndef HSD_STORE_SPREAD
+#define HSD_STORE_SPREAD 0          // 1 (experiment, round 5): a deferred store group leaves ONE store behind each word of its 8-word trip instead of eight in front of it
+#endif
 #ifndef HSD_F64_UNROLL
 #define HSD_F64_UNROLL 4            // columns per straight-line trip of the fp64 inner loops (2 = the plain two-column loop)
 #endif
