@@ -739,7 +739,8 @@ int topk_pruned(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_t *idx_out, d
     //  quantile of 1 024 columns -- and meet n / phases columns there: the unpruned sweep's capacity rule, 4 130 entries at N = 200k; seen with
     //  2 048: one row of rank 7 of 8 appended 2 091 in the first phase, lost its list and the call was repeated unpruned)
     const int64_t phases_dflt = npad / 128 <= 1200 ? 5 : 8;
-    const int64_t cap = std::max<int64_t>(std::max<int64_t>(2048, 512 + 8 * (int64_t)k), block ? 8 * (int64_t)k * n / (1024 * phases_dflt) + 8 * k + 64 : 0);
+    // (the whole graph takes the same rule since round 5: at BA N = 200k its longest list after the first phase was 1 886 of 2 048 entries -- too close)
+    const int64_t cap = std::max<int64_t>(std::max<int64_t>(2048, 512 + 8 * (int64_t)k), 8 * (int64_t)k * n / (1024 * phases_dflt) + 8 * k + 64);
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t oTau = carve((size_t)rows * sizeof(double)), oCnt = carve((size_t)rows * sizeof(int)), oIdx = carve((size_t)rows * cap * sizeof(int));
