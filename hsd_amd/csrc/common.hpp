@@ -170,7 +170,9 @@ struct hsd_ctx {
     // hsd_pair_topk of a prepared distance and released with the operands
     int l1_cols_per_layer = 0;         // PAIR_L1_F64: columns of one histogram layer (the layers follow one another)
     bool tk_ready = false;
-    int32_t *d_tk_orig = nullptr;      // [npad] original node of a position, -1 at padding positions
+    int32_t *d_tk_order = nullptr;     // [npad] the graph's node order (k-d order on the bound's features), -1 at padding positions: built once per prepared
+    bool tk_order_ready = false;       //        distance and kept when the setup is rebuilt for another row block (the expensive part of the setup)
+    int32_t *d_tk_orig = nullptr;      // [tk_npos] original node of a position (the graph's order, then the block's rows), -1 at padding positions
     double *d_tk_X = nullptr;          // [dcols][npad]
     double *d_tk_H = nullptr;          // [npad] ring-0 values in permuted order
     double *d_tk_lo = nullptr, *d_tk_hi = nullptr;   // [tk_nf][tk_nt] feature intervals of the 128-position tiles
@@ -281,7 +283,8 @@ int hsd_launch_khop_ms(hsd_ctx *ctx, int hop, int64_t r0, int64_t r1, uint32_t *
 bool hsd_khop_ms_usable(hsd_ctx *ctx, int hop, int n_bins);
 void hsd_khop_ms_release(hsd_ctx *ctx);
 void hsd_release_operands(hsd_ctx *ctx);
-void hsd_tk_release(hsd_ctx *ctx);
+void hsd_tk_release(hsd_ctx *ctx);            // the pruned k-nearest sweep's whole setup
+void hsd_tk_release_block(hsd_ctx *ctx);      // ... all of it but the graph's node order (another row block is about to be set up)
 int hsd_tk_order_device(hsd_ctx *ctx, const double *d_F, int64_t n, int nf, int32_t *d_order);      // csrc/tkorder.hip
 // positions (of the order d_orig[0 .. npos)) whose node lies in [r0, r1), ascending: d_pos[0 .. r1 - r0) (csrc/tkorder.hip); synchronises
 int hsd_tk_block_positions_device(hsd_ctx *ctx, const int32_t *d_orig, int64_t npos, int64_t r0, int64_t r1, int32_t *d_pos);

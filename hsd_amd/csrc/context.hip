@@ -127,46 +127,104 @@ extern "C" int hsd_create(int device, hsd_ctx **out) try {
 // the pruned k-nearest sweep's node-permuted operand copy (csrc/pair.hip, tk_prepare): released with the operands, and by tk_prepare
 // itself before it builds a new one (a failed attempt leaves nothing behind)
 void hsd_tk_release(hsd_ctx *ctx) {
-    hsd_dev_free(ctx->d_tk_orig);
-    hsd_dev_free(ctx->d_tk_X);
-    hsd_dev_free(ctx->d_tk_H);
-    hsd_dev_free(ctx->d_tk_lo);
-    hsd_dev_free(ctx->d_tk_hi);
-    hsd_dev_free(ctx->d_tk_scale);
-    hsd_dev_free(ctx->d_tk_U);
-    hsd_dev_free(ctx->d_tk_inv);
-    hsd_dev_free(ctx->d_tk_suf);
-    hsd_dev_free(ctx->d_tk_rmax16);
-    hsd_dev_free(ctx->d_tk_gl);
-    hsd_dev_free(ctx->d_tk_tmaxs);
-    if (ctx->d_tk_list) (void)hipFree(ctx->d_tk_list);
-    if (ctx->d_tk_band) (void)hipFree(ctx->d_tk_band);
-    ctx->d_tk_list = ctx->d_tk_band = nullptr;
-    hsd_dev_free(ctx->d_tk_count);
-    hsd_dev_free(ctx->d_tk_tmax);
-    hsd_dev_free(ctx->d_tk_band_lo);
-    hsd_dev_free(ctx->d_tk_band_hi);
+    hsd_tk_release_block(ctx);
+    hsd_op_free(ctx, ctx->d_tk_order);
+    ctx->tk_order_ready = false;
+}
+
+void hsd_tk_release_block(hsd_ctx *ctx) {
+    hsd_op_free(ctx, ctx->d_tk_orig);
+    hsd_op_free(ctx, ctx->d_tk_X);
+    hsd_op_free(ctx, ctx->d_tk_H);
+    hsd_op_free(ctx, ctx->d_tk_lo);
+    hsd_op_free(ctx, ctx->d_tk_hi);
+    hsd_op_free(ctx, ctx->d_tk_scale);
+    hsd_op_free(ctx, ctx->d_tk_U);
+    hsd_op_free(ctx, ctx->d_tk_inv);
+    hsd_op_free(ctx, ctx->d_tk_suf);
+    hsd_op_free(ctx, ctx->d_tk_rmax16);
+    hsd_op_free(ctx, ctx->d_tk_gl);
+    hsd_op_free(ctx, ctx->d_tk_tmaxs);
+    hsd_op_free(ctx, ctx->d_tk_list);
+    hsd_op_free(ctx, ctx->d_tk_band);
+    hsd_op_free(ctx, ctx->d_tk_count);
+    hsd_op_free(ctx, ctx->d_tk_tmax);
+    hsd_op_free(ctx, ctx->d_tk_band_lo);
+    hsd_op_free(ctx, ctx->d_tk_band_hi);
     ctx->tk_ready = false;
     ctx->tk_blk0 = ctx->tk_blk1 = ctx->tk_npos = 0;
     ctx->tk_list_cap = ctx->tk_band_n = ctx->tk_nf = ctx->tk_nt = 0;
 }
 
 void hsd_release_operands(hsd_ctx *ctx) {
-    if (ctx->d_X) (void)hipFree(ctx->d_X);
-    if (ctx->d_Y) (void)hipFree(ctx->d_Y);
-    ctx->d_X = ctx->d_Y = nullptr;
-    hsd_dev_free(ctx->d_H);
-    hsd_dev_free(ctx->d_inv);
-    hsd_dev_free(ctx->d_seg_tab);
-    hsd_dev_free(ctx->d_rmax);
-    hsd_dev_free(ctx->d_rmax16);
-    hsd_dev_free(ctx->d_suf);
+    hsd_op_free(ctx, ctx->d_X);
+    hsd_op_free(ctx, ctx->d_Y);
+    hsd_op_free(ctx, ctx->d_H);
+    hsd_op_free(ctx, ctx->d_inv);
+    hsd_op_free(ctx, ctx->d_seg_tab);
+    hsd_op_free(ctx, ctx->d_rmax);
+    hsd_op_free(ctx, ctx->d_rmax16);
+    hsd_op_free(ctx, ctx->d_suf);
     hsd_tk_release(ctx);
-    for (auto &g : ctx->gran_lists) { (void)hipFree(g.d_gl); (void)hipFree(g.d_tmax); }
+    for (auto &g : ctx->gran_lists) { hsd_op_free(ctx, g.d_gl); hsd_op_free(ctx, g.d_tmax); }
     ctx->gran_lists.clear();
     ctx->gran_order.clear();
     ctx->suf_rows = 0;
     ctx->mode = PAIR_NONE;
+}
+
+// ---- operand arena ----------------------------------------------------------------------------------------------------------
+// Best fit among the unused blocks that are not more than twice the request (+ 1 MiB: the small vectors share a few blocks); otherwise a new block,
+// rounded up to 2 MiB.  When the unused blocks together exceed a quarter of the device's memory they go back to the driver.
+int hsd_pool_alloc(hsd_ctx *ctx, void **p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    int best = -1;
+    for (size_t k = 0; k < ctx->op_pool.size(); ++k) {
+        const auto &b = ctx->op_pool[k];
+        if (b.used || b.bytes < bytes || b.bytes > 2 * bytes + ((size_t)1 << 20)) continue;
+        if (best < 0 || b.bytes < ctx->op_pool[(size_t)best].bytes) best = (int)k;
+    }
+    if (best >= 0) {
+        ctx->op_pool[(size_t)best].used = true;
+        *p = ctx->op_pool[(size_t)best].p;
+        return HSD_OK;
+    }
+    const size_t want = (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) {
+        // the unused blocks may be what stands in the way
+        (void)hipGetLastError();
+        hsd_pool_trim(ctx, false);
+        e = hipMalloc(&q, want);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return hsd_fail(ctx, HSD_ERR_HIP, "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e)); }
+    ctx->op_pool.push_back({q, want, true});
+    *p = q;
+    return HSD_OK;
+}
+
+void hsd_pool_free(hsd_ctx *ctx, void *p) {
+    if (!p) return;
+    for (auto &b : ctx->op_pool)
+        if (b.p == p) {
+            b.used = false;
+            size_t idle = 0;
+            for (const auto &c : ctx->op_pool) if (!c.used) idle += c.bytes;
+            if (idle > ctx->prop.totalGlobalMem / 4) hsd_pool_trim(ctx, false);
+            return;
+        }
+    (void)hipFree(p);                                  // (not from the arena)
+}
+
+void hsd_pool_trim(hsd_ctx *ctx, bool all) {
+    for (size_t k = 0; k < ctx->op_pool.size();) {
+        if (all || !ctx->op_pool[k].used) {
+            (void)hipFree(ctx->op_pool[k].p);
+            ctx->op_pool.erase(ctx->op_pool.begin() + (long)k);
+        } else ++k;
+    }
 }
 
 extern "C" int hsd_comm_destroy_internal(hsd_ctx *ctx);
@@ -177,6 +235,7 @@ extern "C" void hsd_destroy(hsd_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     hsd_comm_destroy_internal(ctx);
     hsd_release_operands(ctx);
+    hsd_pool_trim(ctx, true);
     hsd_heat_release_internal(ctx);
     hsd_dev_free(ctx->d_rowptr);
     hsd_dev_free(ctx->d_col);

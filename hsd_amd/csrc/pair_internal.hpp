@@ -180,13 +180,15 @@ __host__ __device__ inline SegChoice choose_segment_form(const HsdSegDesc &sd, b
 // device temporary of hsd_pair_prepare: released on every exit path
 struct DevTmp {
     void *p = nullptr;
-    ~DevTmp() { if (p) (void)hipFree(p); }
+    hsd_ctx *ctx = nullptr;
+    // (back to the operand arena, not to the driver; the stream is drained first: what hipFree's device-wide synchronisation used to guarantee)
+    ~DevTmp() { if (p && ctx) { (void)hipStreamSynchronize(ctx->stream); hsd_pool_free(ctx, p); } else if (p) (void)hipFree(p); }
     template <typename T> T *as() const { return static_cast<T *>(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    int alloc(hsd_ctx *c, size_t bytes) { ctx = c; return hsd_pool_alloc(c, &p, bytes ? bytes : 1); }
     void *release() { void *q = p; p = nullptr; return q; }
 };
 
-#define HSD_TMP_ALLOC(ctx, tmp, bytes) HSD_HIP(ctx, (tmp).alloc(bytes))
+#define HSD_TMP_ALLOC(ctx, tmp, bytes) do { const int rc_tmp_ = (tmp).alloc((ctx), (bytes)); if (rc_tmp_ != HSD_OK) return rc_tmp_; } while (0)
 
 // ---- host entry points of the launch machinery (csrc/pair.hip) used by the k-nearest consumer and the planner ----
 int tile_edge(const hsd_ctx *ctx);

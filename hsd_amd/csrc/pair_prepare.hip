@@ -270,7 +270,7 @@ int prepare_w1_raw(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int n
     ctx->dcols = (int)round_up(std::max(ctx->dcols_alg, 0), CH);
     ctx->elem_bytes = 8;
     const size_t cnt = (size_t)std::max(ctx->dcols, CH) * p.npad;
-    HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
+    { const int rc_x = hsd_pool_alloc(ctx, &ctx->d_X, cnt * sizeof(double)); if (rc_x) return rc_x; }
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(prep_l1_kernel, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, 0, cpl, ctx->d_H);
     ctx->mode = PAIR_L1_F64;
@@ -318,7 +318,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
     HSD_TMP_ALLOC(ctx, dseg, sizeof(ctx->seg_begin));
     HSD_HIP(ctx, hipMemsetAsync(x0.p, 0, cnt0 * ctx->elem_bytes, ctx->stream));
     HSD_HIP(ctx, hipMemsetAsync(ntot.p, 0, (size_t)nsg * npad * sizeof(uint32_t), ctx->stream));
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_inv, (size_t)nsg * npad))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_inv, (size_t)nsg * npad))) return rc;
     {   // padded nodes: inv = 2 (treated as empty rings; never stored) -- filled on the device (no host buffer whose lifetime an
         // asynchronous copy would depend on; seg_begin lives in the context)
         hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)(((size_t)nsg * npad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_inv, (int64_t)nsg * npad, 2.0);
@@ -345,7 +345,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         const int ngran = (int)(npad / 64);
         DevTmp cmaxd;
         HSD_TMP_ALLOC(ctx, cmaxd, (size_t)ncol32 * sizeof(uint32_t));
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax, (size_t)nl_hist * ngran))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_rmax, (size_t)nl_hist * ngran))) return rc;
         ctx->ngran = ngran;
         hipLaunchKernelGGL(colmax_u32_kernel, dim3((unsigned)ncol32), dim3(256), 0, ctx->stream, x0.as<uint32_t>(), npad, cmaxd.as<uint32_t>());
         std::vector<uint32_t> cmax((size_t)ncol32);
@@ -569,9 +569,9 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             col += (int)round_up(low_w + bp.cap, CH);
             if (pack && u8_ok) { r8_reserved[(size_t)sgi] = col; col += (int)round_up(low_w + bp.cap + 1, CH); }
         }
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_rmax16, (size_t)nl_hist * ngran16))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_rmax16, (size_t)nl_hist * ngran16))) return rc;
         ctx->ngran16 = ngran16;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_suf, (size_t)(suf_rows + 1) * npad))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_suf, (size_t)(suf_rows + 1) * npad))) return rc;
         ctx->suf_rows = suf_rows;
         HSD_HIP(ctx, hipMemsetAsync(ctx->d_suf, 0, (size_t)(suf_rows + 1) * npad * sizeof(uint32_t), ctx->stream));
         HSD_HIP(ctx, hipMemcpyAsync(ctx->d_rmax, rmax_sel.data(), rmax_sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -590,7 +590,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         ctx->dcols_alg = nl_hist * bin_words;
 
         const size_t cntf = (size_t)ctx->dcols * npad;
-        HSD_HIP(ctx, hipMalloc(&ctx->d_X, cntf * sizeof(uint32_t)));
+        { const int rc_x = hsd_pool_alloc(ctx, &ctx->d_X, cntf * sizeof(uint32_t)); if (rc_x) return rc_x; }
         HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cntf * sizeof(uint32_t), ctx->stream));
         if (pack) {
             DevTmp dv;
@@ -727,7 +727,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         ctx->list_cap = 1;
         for (int s = 0; s < nl_hist; ++s) ctx->list_cap += (tab[s].bin_words + CH - 1) / CH + 2;
     }
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_seg_tab, (size_t)nsg))) return rc;
     HSD_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tab, tab, (size_t)nsg * sizeof(HsdSegDesc), hipMemcpyHostToDevice, ctx->stream));
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));              // x0 / ntot / dseg leave scope
     return HSD_OK;
@@ -782,8 +782,8 @@ int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metr
     ctx->dcols_alg = (sym ? 2 : 1) * nl * B;
     ctx->elem_bytes = 8;
     const size_t cnt = (size_t)ctx->dcols * npad;
-    HSD_HIP(ctx, hipMalloc(&ctx->d_X, cnt * sizeof(double)));
-    HSD_HIP(ctx, hipMalloc(&ctx->d_Y, cnt * sizeof(double)));
+    { const int rc_x = hsd_pool_alloc(ctx, &ctx->d_X, cnt * sizeof(double)); if (rc_x) return rc_x; }
+    { const int rc_y = hsd_pool_alloc(ctx, &ctx->d_Y, cnt * sizeof(double)); if (rc_y) return rc_y; }
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_Y, 0, cnt * sizeof(double), ctx->stream));
     DevTmp hpart, sorted;
@@ -817,7 +817,7 @@ int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int lay
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nl), block(256);
     int rc;
     // d_H: per-node entropy term (KL) or the ring-0 point values (W1 with layer 0)
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_H, (size_t)2 * npad))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_H, (size_t)2 * npad))) return rc;
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_H, 0, (size_t)2 * npad * sizeof(double), ctx->stream));
     if (metric == HSD_METRIC_WASSERSTEIN) {
         const int nl_hist = nl - (layer_lo == 0 ? 1 : 0);

@@ -463,7 +463,9 @@ __global__ void tk_tile_interval_kernel(const double *__restrict__ V, const doub
 // rows; its columns are the graph's positions.  One setup is kept per prepared distance: the last block asked for.
 int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
     if (ctx->tk_ready && ctx->tk_blk0 == b0 && ctx->tk_blk1 == b1) return HSD_OK;
-    hsd_tk_release(ctx);                               // (another block's setup, or whatever an earlier, failed attempt allocated)
+    // (another block's setup, or whatever an earlier, failed attempt allocated -- the graph's node order, the expensive part, is kept: a caller that
+    //  walks over row blocks pays ~1 ms per new block at 100k nodes instead of 3-6)
+    hsd_tk_release_block(ctx);
     const bool verbose = hsd_hook(H_TOPK_VERBOSE) != nullptr;
     if (verbose) (void)hipStreamSynchronize(ctx->stream);          // (whatever hsd_pair_prepare left in flight is not this setup's time)
     auto t_last = std::chrono::steady_clock::now();
@@ -540,10 +542,10 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
         mark("block rows in the graph's order");
         return HSD_OK;
     };
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_orig, (size_t)npos))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_lo, (size_t)nf * nt))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_hi, (size_t)nf * nt))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_scale, (size_t)nf * nt))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_orig, (size_t)npos))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_lo, (size_t)nf * nt))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_hi, (size_t)nf * nt))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_scale, (size_t)nf * nt))) return rc;
     if (dev_order) {
         // the order on the device (csrc/tkorder.hip), on V x factor (zero-pad layers: the ring's MEAN value); then every tile's feature intervals
         DevTmp dFo;
@@ -555,13 +557,21 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
             Fo = dFo.as<double>();
         }
         HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_orig, 0xff, (size_t)npos * sizeof(int32_t), ctx->stream));          // padding positions: -1
-        if ((rc = hsd_tk_order_device(ctx, Fo, n, nf, ctx->d_tk_orig))) return rc;
-        mark("k-d order (device)");
+        if (!ctx->tk_order_ready) {
+            if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_order, (size_t)npad))) return rc;
+            HSD_HIP(ctx, hipMemsetAsync(ctx->d_tk_order, 0xff, (size_t)npad * sizeof(int32_t), ctx->stream));
+            if ((rc = hsd_tk_order_device(ctx, Fo, n, nf, ctx->d_tk_order))) return rc;
+            ctx->tk_order_ready = true;
+            mark("k-d order (device)");
+        }
+        HSD_HIP(ctx, hipMemcpyAsync(ctx->d_tk_orig, ctx->d_tk_order, (size_t)npad * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
         if ((rc = block_positions())) return rc;
         hipLaunchKernelGGL(tk_tile_interval_kernel, dim3((unsigned)nt, (unsigned)nf), dim3(128), 0, ctx->stream, dV.as<double>(), seg ? (const double *)ctx->d_inv : nullptr,
                            npad, n, seg ? nlay : 0, (const int32_t *)ctx->d_tk_orig, nt, ctx->d_tk_lo, ctx->d_tk_hi, ctx->d_tk_scale);
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (dFo goes)
     } else {
+        hsd_op_free(ctx, ctx->d_tk_order);              // (the host path keeps no order: HSD_TOPK_ORDER=0 is an A/B hook)
+        ctx->tk_order_ready = false;
         std::vector<int32_t> idx;
         {
             std::vector<double> Fo = V;
@@ -612,20 +622,20 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
             }
             for (int c = blo[(size_t)t]; c <= bhi[(size_t)t]; ++c) band.push_back(make_int2(t, c));
         }
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_band_lo, (size_t)bt))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_band_hi, (size_t)bt))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_band_lo, (size_t)bt))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_band_hi, (size_t)bt))) return rc;
         HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band_lo, blo.data(), blo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band_hi, bhi.data(), bhi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     ctx->tk_band_w = band_w;
     mark("tile intervals + first-launch list");
     if (hsd_hook(H_TOPK_NOMEM)) return hsd_fail(ctx, HSD_ERR_HIP, "hipMalloc: out of memory (HSD_TOPK_NOMEM rehearsal)");
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_H, (size_t)npos))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
-    if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_H, (size_t)npos))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_tmax, (size_t)nt))) return rc;
+    if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_count, (size_t)4))) return rc;
     ctx->tk_list_cap = (int)std::min<int64_t>(bm == 0 ? (int64_t)nt * (nt + 1) / 2 : (bpad / 128) * (int64_t)nt_graph, 0x7fffffff);
-    HSD_HIP(ctx, hipMalloc(&ctx->d_tk_list, (size_t)ctx->tk_list_cap * sizeof(int2)));
-    HSD_HIP(ctx, hipMalloc(&ctx->d_tk_band, band.size() * sizeof(int2)));
+    { const int rc_l = hsd_pool_alloc(ctx, &ctx->d_tk_list, (size_t)ctx->tk_list_cap * sizeof(int2)); if (rc_l) return rc_l; }
+    { const int rc_b = hsd_pool_alloc(ctx, &ctx->d_tk_band, band.size() * sizeof(int2)); if (rc_b) return rc_b; }
     ctx->tk_band_n = (int)band.size();
     HSD_HIP(ctx, hipMemcpy(ctx->d_tk_band, band.data(), band.size() * sizeof(int2), hipMemcpyHostToDevice));
     const dim3 pgrid((unsigned)((npos + 255) / 256));
@@ -633,12 +643,12 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
         hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, 1u), dim3(256), 0, ctx->stream, (const double *)ctx->d_H, npad, ctx->d_tk_orig, npos, ctx->d_tk_H);
     if (!seg) {
         const int cols = std::max(ctx->dcols, 16);
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_X, (size_t)cols * npos))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_X, (size_t)cols * npos))) return rc;
         hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const double *)ctx->d_X, npad, ctx->d_tk_orig, npos, ctx->d_tk_X);
         if (bm > 0) {
             // (a row block's rectangle names its tiles by the positions' own granule list -- the graph's list ends with the graph)
             const int ngran16 = (int)(npos / 16);
-            if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
+            if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
             std::vector<int32_t> gl((size_t)ngran16);
             for (int g = 0; g < ngran16; ++g) gl[(size_t)g] = g;
             HSD_HIP(ctx, hipMemcpy(ctx->d_tk_gl, gl.data(), gl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -648,12 +658,12 @@ int tk_prepare(hsd_ctx *ctx, int64_t b0, int64_t b1) {
         // members above each layer's threshold per position -> maxima per 16-position granule (+ the "too wide for the uint8 range" flags) -> per tile
         const int cols = std::max(ctx->dcols, 32), ngran16 = (int)(npos / 16);
         const int64_t sufr = (int64_t)ctx->suf_rows + 1;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_U, (size_t)cols * npos))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_inv, (size_t)nlay * npos))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_suf, (size_t)sufr * npos))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_rmax16, (size_t)nlay * ngran16))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
-        if ((rc = hsd_dev_alloc(ctx, &ctx->d_tk_tmaxs, (size_t)nlay * nt))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_U, (size_t)cols * npos))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_inv, (size_t)nlay * npos))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_suf, (size_t)sufr * npos))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_rmax16, (size_t)nlay * ngran16))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_gl, (size_t)ngran16))) return rc;
+        if ((rc = hsd_op_alloc(ctx, &ctx->d_tk_tmaxs, (size_t)nlay * nt))) return rc;
         hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)cols), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_X, npad, ctx->d_tk_orig, npos, ctx->d_tk_U);
         hipLaunchKernelGGL(tk_gather_kernel, dim3(pgrid.x, (unsigned)nlay), dim3(256), 0, ctx->stream, (const double *)ctx->d_inv, npad, ctx->d_tk_orig, npos, ctx->d_tk_inv);
         if (ctx->d_suf) hipLaunchKernelGGL(tk_gather_u32_kernel, dim3(pgrid.x, (unsigned)sufr), dim3(256), 0, ctx->stream, ctx->d_suf, npad, ctx->d_tk_orig, npos, ctx->d_tk_suf);
