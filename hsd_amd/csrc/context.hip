@@ -174,15 +174,18 @@ void hsd_release_operands(hsd_ctx *ctx) {
 }
 
 // ---- operand arena ----------------------------------------------------------------------------------------------------------
-// Best fit among the unused blocks that are not more than twice the request (+ 1 MiB: the small vectors share a few blocks); otherwise a new block,
-// rounded up to 2 MiB.  When the unused blocks together exceed a quarter of the device's memory they go back to the driver.
+// Best fit among the unused blocks of up to twice the request's own block size (requests are rounded up to 256 KiB below 2 MiB, to 2 MiB above: the few
+// hundred small vectors of a prepare share a handful of sizes); otherwise a new block.  When the unused blocks together exceed a quarter of the device's
+// memory they go back to the driver.
 int hsd_pool_alloc(hsd_ctx *ctx, void **p, size_t bytes) {
     *p = nullptr;
     if (bytes == 0) bytes = 1;
+    const size_t gran = bytes < ((size_t)2 << 20) ? ((size_t)256 << 10) : ((size_t)2 << 20);
+    const size_t want = (bytes + gran - 1) / gran * gran;
     int best = -1;
     for (size_t k = 0; k < ctx->op_pool.size(); ++k) {
         const auto &b = ctx->op_pool[k];
-        if (b.used || b.bytes < bytes || b.bytes > 2 * bytes + ((size_t)1 << 20)) continue;
+        if (b.used || b.bytes < bytes || b.bytes > 2 * want) continue;
         if (best < 0 || b.bytes < ctx->op_pool[(size_t)best].bytes) best = (int)k;
     }
     if (best >= 0) {
@@ -190,7 +193,6 @@ int hsd_pool_alloc(hsd_ctx *ctx, void **p, size_t bytes) {
         *p = ctx->op_pool[(size_t)best].p;
         return HSD_OK;
     }
-    const size_t want = (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, want);
     if (e != hipSuccess) {
@@ -202,6 +204,11 @@ int hsd_pool_alloc(hsd_ctx *ctx, void **p, size_t bytes) {
     if (e != hipSuccess) { (void)hipGetLastError(); return hsd_fail(ctx, HSD_ERR_HIP, "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e)); }
     ctx->op_pool.push_back({q, want, true});
     *p = q;
+    if (hsd_hook(H_PLAN_VERBOSE)) {
+        size_t total = 0;
+        for (const auto &b : ctx->op_pool) total += b.bytes;
+        fprintf(stderr, "[hsd pool] new block of %zu bytes (asked %zu): %zu blocks, %.1f MB\n", want, bytes, ctx->op_pool.size(), (double)total / 1e6);
+    }
     return HSD_OK;
 }
 

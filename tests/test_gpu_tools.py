@@ -173,3 +173,48 @@ def test_single_node_structure_and_index_maps(engine, capsys):
     idx2node, node2idx = tools.build_node_idx_map(g)
     assert [idx2node[i] for i in range(g.n_node)] == g.nodes and all(node2idx[v] == i for i, v in enumerate(g.nodes))
     assert tools.scale_boundary(1.0, 4.0) == (-np.log(0.95) / 2.0, -np.log(0.85) / 2.0)
+
+
+def test_operand_arena_reuses_its_blocks(engine):
+    """hsd_pair_prepare takes its operand sets, the k-nearest sweep's permuted copies and its temporaries from the context's grow-only arena (csrc/context.hip,
+    hsd_pool_*): cycling through three distances and their k-nearest setups again and again must not take more device memory than the first cycle did, and
+    the results stay what they were."""
+    import ctypes
+    from hsd_amd.graph import barabasi_albert
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+    g = barabasi_albert(12000, 5, 21)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    first = {}
+    os.environ["HSD_STREAM"] = "1"
+    os.environ["HSD_TOPK_PRUNE"] = "1"
+    try:
+        def cycle(check):
+            for name, mode in (("B", (0, 1, 0, 2)), ("A", (0, 0, 0, 3)), ("KL", (2, 0, 0, 3, 0.5, False))):
+                engine.pair_prepare(*mode)
+                row = engine.pair_rows_host(100, 101)[0]
+                idx, val = engine.pair_topk(7) if name != "KL" else (None, None)
+                blk = engine.pair_topk(7, 2048, 6000) if name != "KL" else None
+                if not check:
+                    first[name] = (row, idx, val, blk)
+                else:
+                    assert np.array_equal(row, first[name][0])
+                    if idx is not None:
+                        assert np.array_equal(idx, first[name][1]) and np.array_equal(val, first[name][2])
+                        assert np.array_equal(blk[0], first[name][3][0]) and np.array_equal(blk[1], first[name][3][1])
+        cycle(False)
+        cycle(True)
+        engine.sync()
+        after_two = free_bytes()
+        for _ in range(6):
+            cycle(True)
+        engine.sync()
+        assert free_bytes() >= after_two - (64 << 20), (after_two, free_bytes())
+    finally:
+        os.environ.pop("HSD_STREAM", None)
+        os.environ.pop("HSD_TOPK_PRUNE", None)
