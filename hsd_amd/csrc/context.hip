@@ -133,6 +133,9 @@ void hsd_tk_release(hsd_ctx *ctx) {
 }
 
 void hsd_tk_release_block(hsd_ctx *ctx) {
+    // (a block that goes back to the arena may be handed out again at once: nothing in flight may still read it -- hipFree used to see to that by
+    //  synchronising the device; the context's stream is where everything that reads operands runs or is joined)
+    if (ctx->stream && ctx->d_tk_orig) (void)hipStreamSynchronize(ctx->stream);
     hsd_op_free(ctx, ctx->d_tk_orig);
     hsd_op_free(ctx, ctx->d_tk_X);
     hsd_op_free(ctx, ctx->d_tk_H);
@@ -157,6 +160,7 @@ void hsd_tk_release_block(hsd_ctx *ctx) {
 }
 
 void hsd_release_operands(hsd_ctx *ctx) {
+    if (ctx->stream && (ctx->d_X || ctx->d_H)) (void)hipStreamSynchronize(ctx->stream);      // (see hsd_tk_release_block)
     hsd_op_free(ctx, ctx->d_X);
     hsd_op_free(ctx, ctx->d_Y);
     hsd_op_free(ctx, ctx->d_H);
