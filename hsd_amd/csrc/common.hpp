@@ -132,6 +132,10 @@ struct hsd_ctx {
     bool has_point = false;            // W1 with layer 0: ring-0 values live in d_H and add |p_i - p_j|; KL with layer 0 in closed
                                        // form: they follow the entropy term (d_H + npad) and add kl_point_c where they differ
     double kl_point_c = 0.0;
+    // KL kinds, sparse-column form (prepare_kl): occupancy of the columns of one half per 16-node granule [npad / 16][kl_words] (nullptr: dense form),
+    // where the second half starts (symmetric KL; 0: one half), data columns of a half
+    unsigned long long *d_kl_mask = nullptr;
+    int kl_words = 0, kl_half = 0, kl_half_alg = 0;
     int seg_begin[HSD_MAX_LAYERS + 1] = {0};   // column range of each segment (chunk aligned)
     int *d_flag = nullptr;             // device error flag (empty ring, ...)
 

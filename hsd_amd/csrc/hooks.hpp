@@ -39,6 +39,7 @@ enum HsdHook {
     H_U8,
     H_SHARD_BALANCE,
     H_KL_POINT,
+    H_KL_TRIM,
     H_DEBUG,
     H_SIDE_STREAMS,
     H_TOPK_DEBUG,

@@ -691,6 +691,11 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     T *sbase = reinterpret_cast<T *>(lds_raw);
     int2 *clist = reinterpret_cast<int2 *>(sbase + 2 * STAGE);   // [2][list_cap]: chunk lists of the current and the next tile
     int *nlist = reinterpret_cast<int *>(clist + 2 * a.list_cap);   // [2]: their lengths; [2]: the tile index drawn for the tile after next
+    // KL kinds, sparse-column form: the tile pair's column list -- ids (uint16, within one half) of the columns occupied on BOTH sides, in the chunk-list
+    // area of LDS: buffer `buf` holds up to 4 x list_cap ids, nlist[buf] their number
+    const bool ktrim = KIND == K_DOT && a.kmask != nullptr;
+    uint16_t *const klist = reinterpret_cast<uint16_t *>(clist);
+    const int kcap = 4 * a.list_cap;
     // [3][24] ring (current tile, next, the one after): the tile's granules (0-7: I side, 8-15: J side), per layer segment
     // the most members above its threshold on the I side (16-19) and on the J side (20-23; bit 31: see plan_segment_min)
     int *meta = nlist + 4;
@@ -791,6 +796,31 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
         asm volatile("" ::: "memory");               // no load / store moves across the request: vm_seq below relies on the order
         const uint32_t dst_lds = lds_base + (uint32_t)(st * STAGE * sizeof(T));
         int issued = 0;
+        if constexpr (KIND == K_DOT) {
+            if (ktrim) {
+                // sparse-column form: slot `ins` of the stage holds column list[16 chunk + ins] (+ the second half's offset); wave w takes the slots
+                // 4 w .. 4 w + 3, whose ids are one 8-byte LDS read
+                static_assert(COLS == 1 && CH == 16 && NW == 4, "one fp64 column per instruction, four per wave and chunk");
+                const int buf_ = col >> 20, kq = col & 0xfffff;
+                const int cnt = __builtin_amdgcn_readfirstlane(nlist[buf_]), nh = (cnt + CH - 1) / CH;
+                const bool second = a.khalf && kq >= nh;
+                const int kk = second ? kq - nh : kq;
+                const unsigned long long four = *reinterpret_cast<const unsigned long long *>(klist + buf_ * kcap + kk * CH + 4 * w);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)four), hi = __builtin_amdgcn_readfirstlane((uint32_t)(four >> 32));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ins = 4 * w + k;
+                    const int id = (int)(((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0xffffu) + (second ? a.khalf : 0);
+                    if (ins < valid) {
+                        glds16_s(reinterpret_cast<uint64_t>(XI + (int64_t)id * a.npad), offI, dst_lds + (uint32_t)(ins * BT * sizeof(T)));
+                        glds16_s(reinterpret_cast<uint64_t>(XJ + (int64_t)id * a.npad), offJ, dst_lds + (uint32_t)((CH * BT + ins * BT) * sizeof(T)));
+                        issued += 2;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                return issued;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < CH / COLS / NW; ++k) {
             const int ins = k * NW + w;
@@ -876,18 +906,58 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             const int pre = plan_segment_min<CH, KIND == K_SAD16>(sd, l < a.n_seg, RI, RJ, l, clist + buf * a.list_cap, smeta + buf * 4);
             if (l == 0) nlist[buf] = pre;
         }
+        if constexpr (KIND == K_DOT) {
+            if (!ktrim || w != 0) return;
+            // lane l < kwords: word l of (OR of the I side's eight granules) AND (OR of the J side's); then the set bits as column ids, lane by lane
+            // behind an exclusive prefix of the lanes' counts.  (Plain loads: a KL tile runs for ~10^5 cycles, a memory latency here is nothing.)
+            const int l = lane();
+            unsigned long long mi = 0ull, mj = 0ull;
+            if (l < a.kwords) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    mi |= a.kmask[(int64_t)meta[ms * META + e] * a.kwords + l];
+                    mj |= a.kmask[(int64_t)meta[ms * META + 8 + e] * a.kwords + l];
+                }
+            }
+            unsigned long long both = mi & mj;
+            const int cnt = __popcll(both);
+            int pre = cnt;                             // inclusive prefix over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(pre, d, 64);
+                if (l >= d) pre += o;
+            }
+            const int total = __shfl(pre, 63, 64);
+            int at = pre - cnt;
+            uint16_t *out = klist + buf * kcap;
+            while (both) {
+                const int q = __builtin_ctzll(both);
+                both &= both - 1;
+                out[at++] = (uint16_t)(64 * l + q);
+            }
+            if (l == 0) nlist[buf] = total;
+        }
     };
     auto planned_chunks = [&](int buf) __attribute__((always_inline)) -> int {
         if constexpr (SEG) return __builtin_amdgcn_readfirstlane(nlist[buf]);
-        else return (a.dcols_valid + CH - 1) / CH;
+        else if (ktrim) {
+            const int nh = (__builtin_amdgcn_readfirstlane(nlist[buf]) + CH - 1) / CH;
+            return a.khalf ? 2 * nh : nh;
+        } else return (a.dcols_valid + CH - 1) / CH;
     };
+    // (sparse-column form: the "column" of a chunk is its place in the list -- buffer << 20 | chunk --, stage_chunk looks the ids up)
     auto chunk_col = [&](int buf, int k) __attribute__((always_inline)) -> int {
         if constexpr (SEG) return __builtin_amdgcn_readfirstlane(clist[buf * a.list_cap + k].x);
+        else if (ktrim) return (buf << 20) | k;
         else return k * CH;
     };
     auto chunk_valid = [&](int buf, int k) __attribute__((always_inline)) -> int {
         if constexpr (SEG) return __builtin_amdgcn_readfirstlane(clist[buf * a.list_cap + k].y) & 0xff;
-        else return min(CH, a.dcols_valid - k * CH);
+        else if (ktrim) {
+            const int cnt = __builtin_amdgcn_readfirstlane(nlist[buf]), nh = (cnt + CH - 1) / CH;
+            const int kk = (a.khalf && k >= nh) ? k - nh : k;
+            return min(CH, cnt - kk * CH);
+        } else return min(CH, a.dcols_valid - k * CH);
     };
 
     // ---- prologue: plan of the first tile, coordinates of the next two ----
@@ -1161,7 +1231,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
                 n16 = (meta >> 9) & 0x3f;                 // leading words of uint16 pairs; the rest are uint8 quadruples
                 seg = meta >> 16;
             } else {
-                cvalid = min(CH, a.dcols_valid - k * CH);
+                cvalid = chunk_valid(cur, k);
             }
             work += (unsigned)cvalid;
             if (a.dbg & 2) cvalid = n16 = 0;
@@ -2270,6 +2340,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
     a.inv = ctx->d_inv;
     a.point = ctx->has_point ? (wass ? ctx->d_H : ctx->d_H + ctx->npad) : nullptr;
     a.point_c = ctx->kl_point_c;
+    a.kmask = wass ? nullptr : ctx->d_kl_mask; a.kwords = ctx->kl_words; a.khalf = ctx->kl_half;
     a.npad = ctx->npad;
     a.dcols = ctx->dcols;
     a.n_seg = ctx->n_seg;

@@ -46,6 +46,10 @@ struct PairArgs {
     const double *inv;      // segmented: [n_seg][npad]
     const double *point;    // optional ring-0 value per node [npad] (W1: adds |p_i - p_j|; DOT: adds point_c where p_i != p_j)
     double point_c;         // DOT: KL of two different point masses on the smoothed support (closed form of layer 0, prepare_kl)
+    // DOT, sparse-column form (persistent kernel): occupancy masks of one half's columns per 16-node granule [granule][kwords] -- a tile pair runs only
+    // over the columns occupied on BOTH of its sides --, and the column offset of the second half (symmetric KL: the same list once more; 0: none)
+    const unsigned long long *kmask;
+    int kwords, khalf;
     double *out;
     int64_t ld, npad;
     int64_t rbase;          // out row 0 <-> node rbase

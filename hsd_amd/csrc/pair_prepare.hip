@@ -206,6 +206,91 @@ __global__ void sum_layers_kernel(const double *__restrict__ Hpart, int nl, int6
     H[i] = s;
 }
 
+// KL, the form whose columns are SPARSE where the histograms are (round 5: per-tile column trimming in the persistent kernel).
+// With P = (c + alpha) / Z, Z = n + alpha B, and m(b) = log(c(b) + alpha) - log alpha (0 exactly where the bin is empty):
+//   sum_b P_i(b) log P_j(b) = [ sum_b c_i(b) m_j(b)  +  n_i log alpha  +  alpha L_j ] / Z_i  -  log Z_j ,   L_j = sum_b log(c_j(b) + alpha)
+// so per layer kk the columns are  X = c / Z, Y = m  (a product is non-zero only in bins occupied on BOTH sides), one more column
+// X = alpha / Z, Y = L, and -- once for all layers -- X = 1, Y = -sum_kk log Z; the term n_i log alpha / Z_i goes into the entropy term
+// H'_i = sum_kk (sum_b P log P - n log alpha / Z).  KL(i || j) = H'_i - X_i . Y_j as before.  symmetric: X = [X ; Y], Y = [Y ; X].
+// Adding an exact zero leaves an fp64 sum unchanged, so a kernel that skips the columns empty on either side of a tile pair and one that
+// runs over all of them give the same bits.
+__global__ void prep_kl_sparse_kernel(PrepArgs p, double alpha, int symmetric, int nl, int half_cols /* padded columns of one half */,
+                                      double *__restrict__ X, double *__restrict__ Y, double *__restrict__ Hpart /* [nl][npad] */,
+                                      double *__restrict__ LZpart /* [nl][npad]: log Z */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kk = blockIdx.y;
+    const int k = p.layer_lo + kk;
+    if (i >= p.n) return;
+    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
+    uint32_t tot = 0;
+    for (int b = 0; b < p.B; ++b) tot += c[b];
+    const double Z = (double)tot + alpha * (double)p.B, la = log(alpha);
+    double h = 0.0, Ls = 0.0;
+    for (int b = 0; b < p.B; ++b) {
+        const double lc = log((double)c[b] + alpha);
+        const double P = ((double)c[b] + alpha) / Z;
+        h += P * (lc - log(Z));
+        Ls += lc;
+        const int64_t col = (int64_t)kk * p.B + b;
+        const double x = (double)c[b] / Z, y = c[b] ? lc - la : 0.0;
+        X[col * p.npad + i] = x;
+        Y[col * p.npad + i] = y;
+        if (symmetric) {
+            X[(half_cols + col) * p.npad + i] = y;
+            Y[(half_cols + col) * p.npad + i] = x;
+        }
+    }
+    const int64_t ce = (int64_t)nl * p.B + kk;
+    X[ce * p.npad + i] = alpha / Z;
+    Y[ce * p.npad + i] = Ls;
+    if (symmetric) {
+        X[(half_cols + ce) * p.npad + i] = Ls;
+        Y[(half_cols + ce) * p.npad + i] = alpha / Z;
+    }
+    Hpart[(int64_t)kk * p.npad + i] = h - (double)tot * la / Z;
+    LZpart[(int64_t)kk * p.npad + i] = log(Z);
+}
+
+// the column X = 1, Y = -sum_kk log Z (symmetric: mirrored into the second half)
+__global__ void kl_logz_column_kernel(const double *__restrict__ LZpart, int nl, int64_t npad, int64_t n, int64_t col, int symmetric, int half_cols,
+                                      double *__restrict__ X, double *__restrict__ Y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double g = 0.0;
+    for (int k = 0; k < nl; ++k) g += LZpart[(int64_t)k * npad + i];
+    X[col * npad + i] = 1.0;
+    Y[col * npad + i] = -g;
+    if (symmetric) {
+        X[(half_cols + col) * npad + i] = -g;
+        Y[(half_cols + col) * npad + i] = 1.0;
+    }
+}
+
+// mask[g][w]: bit q set <=> column 64 w + q of a half is occupied by one of the 16 nodes of granule g (histogram columns: a count > 0; the
+// nl + 1 columns behind them: always).  The persistent kernel ORs a tile side's eight granules and ANDs the two sides.
+__global__ void kl_mask_kernel(PrepArgs p, int nl, int kwords, int64_t ngran16, unsigned long long *__restrict__ mask) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ngran16 * kwords) return;
+    const int64_t g = t / kwords;
+    const int w = (int)(t % kwords);
+    const int hist_cols = nl * p.B, all_cols = hist_cols + nl + 1;
+    unsigned long long m = 0ull;
+    for (int q = 0; q < 64; ++q) {
+        const int col = 64 * w + q;
+        if (col >= all_cols) break;
+        bool on = col >= hist_cols;
+        if (!on) {
+            const int kk = col / p.B, b = col % p.B;
+            for (int e = 0; e < 16 && !on; ++e) {
+                const int64_t i = 16 * g + e;
+                on = i < p.n && p.counts[((int64_t)i * p.L + p.layer_lo + kk) * p.B + b] > 0u;
+            }
+        }
+        if (on) m |= 1ull << q;
+    }
+    mask[t] = m;
+}
+
 // ascending sort of each (node, layer) histogram -- tools/metrics.py:29-30 applied to the
 // probability vectors (a monotone map of the counts, so sorting counts is equivalent)
 __global__ void sort_counts_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int B, int Bp2) {
@@ -777,10 +862,17 @@ int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metr
             ctx->kl_point_c = (log((1.0 + kl_alpha) / kl_alpha)) / (1.0 + kl_alpha * (double)B);
         }
     }
-    const int half = (int)round_up((int64_t)nl * B, CH);
+    // sparse-column form + per-tile column trimming (needs alpha > 0: log alpha; HSD_KL_TRIM=0: the dense form P . log P)
+    const bool sparse = kl_alpha > 0.0 && hsd_hook_int(H_KL_TRIM, 1) != 0;
+    const int half_alg = sparse ? nl * B + nl + 1 : nl * B;
+    const int half = (int)round_up((int64_t)half_alg, CH);
     ctx->dcols = sym ? 2 * half : half;
-    ctx->dcols_alg = (sym ? 2 : 1) * nl * B;
+    ctx->dcols_alg = (sym ? 2 : 1) * half_alg;
     ctx->elem_bytes = 8;
+    hsd_op_free(ctx, ctx->d_kl_mask);
+    ctx->kl_words = 0;
+    ctx->kl_half = sym ? half : 0;
+    ctx->kl_half_alg = half_alg;
     const size_t cnt = (size_t)ctx->dcols * npad;
     { const int rc_x = hsd_pool_alloc(ctx, &ctx->d_X, cnt * sizeof(double)); if (rc_x) return rc_x; }
     { const int rc_y = hsd_pool_alloc(ctx, &ctx->d_Y, cnt * sizeof(double)); if (rc_y) return rc_y; }
@@ -796,8 +888,26 @@ int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metr
                            (size_t)Bp2 * sizeof(uint32_t), ctx->stream, ctx->d_counts, sorted.as<uint32_t>(), B, Bp2);
         p.counts = sorted.as<uint32_t>();
     }
-    hipLaunchKernelGGL(prep_kl_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
-                       (double *)ctx->d_Y, hpart.as<double>());
+    if (!sparse) {
+        hipLaunchKernelGGL(prep_kl_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
+                           (double *)ctx->d_Y, hpart.as<double>());
+    } else {
+        DevTmp lz;
+        HSD_TMP_ALLOC(ctx, lz, (size_t)nl * npad * sizeof(double));
+        hipLaunchKernelGGL(prep_kl_sparse_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, nl, half, (double *)ctx->d_X, (double *)ctx->d_Y,
+                           hpart.as<double>(), lz.as<double>());
+        hipLaunchKernelGGL(kl_logz_column_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, (const double *)lz.as<double>(), nl, npad, n,
+                           (int64_t)nl * B + nl, sym, half, (double *)ctx->d_X, (double *)ctx->d_Y);
+        // occupancy masks per 16-node granule; the tile's column list lives in the kernel's chunk-list area as uint16 ids
+        const int kwords = (half_alg + 63) / 64;
+        const int64_t ngran16 = npad / 16;
+        int rc_m;
+        if ((rc_m = hsd_op_alloc(ctx, &ctx->d_kl_mask, (size_t)ngran16 * kwords))) return rc_m;
+        hipLaunchKernelGGL(kl_mask_kernel, dim3((unsigned)((ngran16 * kwords + 255) / 256)), block, 0, ctx->stream, p, nl, kwords, ngran16, ctx->d_kl_mask);
+        ctx->kl_words = kwords;
+        ctx->list_cap = (half_alg * 2 + 7) / 8 + 2;              // int2 entries per list buffer: half_alg uint16 ids (+ slack for a whole last chunk)
+        HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (lz goes)
+    }
     hipLaunchKernelGGL(sum_layers_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, hpart.as<double>(), nl, npad, n, ctx->d_H);
     HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));              // temporaries leave scope
     ctx->mode = sym ? PAIR_SKL : PAIR_KL;

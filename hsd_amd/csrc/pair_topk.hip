@@ -925,6 +925,7 @@ extern "C" int hsd_pair_topk(hsd_ctx *ctx, int k, int64_t r0, int64_t r1, int32_
     a.inv = ctx->d_inv;
     a.point = ctx->has_point ? (wass ? ctx->d_H : ctx->d_H + ctx->npad) : nullptr;
     a.point_c = ctx->kl_point_c;
+    a.kmask = wass ? nullptr : ctx->d_kl_mask; a.kwords = ctx->kl_words; a.khalf = ctx->kl_half;
     a.npad = ctx->npad;
     a.dcols = ctx->dcols;
     a.n_seg = ctx->n_seg;

@@ -170,14 +170,16 @@ def test_kl_ring0_closed_form_equals_the_dense_layer(engine, n, p, K):
             dense, dense_blk, cols_dense = _with_env("HSD_KL_POINT", "0", lambda: matrix("1"))
             for stream in ("1", "0"):
                 D, blk, cols = matrix(stream)
-                assert cols_dense == (metric == 2 and 2 or 1) * (K + 1) * B
-                assert cols == (metric == 2 and 2 or 1) * K * B + (0 if srt else 1)
+                # (columns of a half: the layers' bins + -- sparse-column form, round 5 -- one column per layer and one for all of them)
+                f = 2 if metric == 2 else 1
+                assert cols_dense == f * ((K + 1) * B + (K + 1) + 1)
+                assert cols == f * (K * B + K + 1) + (0 if srt else 1)
                 assert np.allclose(D, dense, rtol=1e-12, atol=1e-13), (metric, alpha, srt, stream, np.abs(D - dense).max())
                 assert np.allclose(blk, dense_blk, rtol=1e-12, atol=1e-13)
                 assert np.array_equal(blk, D[n // 3:n // 3 + 200]) or metric == 2
     # ring 0 alone (layers 0..0) and alpha = 0 keep the dense loop (nothing else to compute / log 0)
     engine.pair_prepare(1, 0, 0, 0, 0.5, False)
-    assert engine.pair_operand_dims()[0] == B
+    assert engine.pair_operand_dims()[0] == B + 2
     D0 = engine.pair_rows_host()
     deg = g.degree
     want = np.where(deg[:, None] != deg[None, :], np.log(1.5 / 0.5) / (1 + 0.5 * B), 0.0)
@@ -196,13 +198,13 @@ def test_kl_ring0_closed_form_needs_ring0_to_be_the_node(engine):
     counts[17, 0] = counts[17, 1]                  # node 17's "ring 0" is its neighbourhood
     engine.signature_set_counts(0, g.n_node, counts)
     engine.pair_prepare(1, 0, 0, 2, 0.5, False)
-    assert engine.pair_operand_dims()[0] == 3 * B
+    assert engine.pair_operand_dims()[0] == 3 * B + 3 + 1
     D = engine.pair_rows_host()
     ref = _with_env("HSD_KL_POINT", "0", lambda: (engine.pair_prepare(1, 0, 0, 2, 0.5, False), engine.pair_rows_host())[1])
     assert np.array_equal(D, ref)
     engine.signature_build_degree(2)               # back to the graph's own rings: closed form again
     engine.pair_prepare(1, 0, 0, 2, 0.5, False)
-    assert engine.pair_operand_dims()[0] == 2 * B + 1
+    assert engine.pair_operand_dims()[0] == 2 * B + 2 + 1 + 1
 
 
 @pytest.mark.parametrize("n,p,K,seed", [(2000, 0.004, 3, 1), (3001, 0.003, 2, 2), (777, 0.02, 3, 3)])
@@ -516,3 +518,46 @@ def test_contexts_return_their_hbm(engine):
         cycle()
     after = free_bytes()
     assert before - after < 32 << 20, (before, after, before - after)
+
+
+@pytest.mark.parametrize("n,p,K", [(6000, None, 3), (1111, 0.01, 2)], ids=["scale-free", "erdos-renyi"])
+def test_kl_sparse_columns_and_tile_trimming(engine, n, p, K):
+    """Round 5: the KL kinds' operands in the sparse-column form (X = c / Z, Y = log(c + alpha) - log alpha: zero wherever a bin is empty) and the persistent
+    kernel running a tile pair only over the columns occupied on BOTH of its sides.  Skipped products are exact zeros, so the trimmed persistent kernel,
+    the same kernel over every column and the one-tile kernel give the same bits; against the dense form (HSD_KL_TRIM=0: P . log P) the difference is the
+    rounding of a re-associated sum; the kernel's own column count shows that columns were in fact skipped."""
+    from hsd_amd.graph import barabasi_albert, erdos_renyi
+    g = erdos_renyi(n, p, 12) if p else barabasi_albert(n, 4, 12)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(K)
+    for metric in (1, 2):
+        for alpha, srt in ((0.5, False), (0.05, False), (0.5, True)):
+            def run(stream):
+                def f():
+                    engine.pair_prepare(metric, 0, 0, K, alpha, srt)
+                    D = engine.pair_rows_host()
+                    cols = engine.pair_operand_dims()[0]
+                    M = engine.pair_rows_device()
+                    try:
+                        work = engine.pair_work() / (n * (n - 1) / 2.0)
+                    finally:
+                        M.free()
+                    return D, cols, work
+                return _with_env("HSD_STREAM", stream, f)
+            trimmed, cols, work = run("1")
+            one_tile, _, _ = run("0")
+            assert np.array_equal(trimmed, one_tile), (metric, alpha, srt)
+            if p is None:
+                assert work < 0.99 * cols, (work, cols)                     # columns were skipped (3 % at this size; 27 % at config 3: outer rings of a large graph hold few hubs)
+            dense, dcols, dwork = _with_env("HSD_KL_TRIM", "0", lambda: run("1"))
+            assert dcols < cols and (p is not None or dwork > work)
+            assert np.allclose(trimmed, dense, rtol=1e-9, atol=1e-12), np.abs(trimmed - dense).max()
+    # alpha = 0 keeps the dense form (log 0): whatever it returns or raises, both settings agree
+    def a0():
+        try:
+            engine.pair_prepare(1, 0, 1, K, 0.0, False)
+            return engine.pair_rows_host(0, 8)
+        except ValueError as e:
+            return str(e)
+    r1, r0 = a0(), _with_env("HSD_KL_TRIM", "0", a0)
+    assert (isinstance(r1, str) and r1 == r0) or np.array_equal(r1, r0, equal_nan=True)
