@@ -179,6 +179,65 @@ struct WaveList {
     }
 };
 
+// A list of up to 64 E (value, index) entries SORTED across the wave (round 5): element p = 64 e + lane of a bitonic network over 64 E places -- a
+// compare-exchange with a partner in another lane is three cross-lane moves, one in the same lane none; 21 / 28 / 36 / 45 stages for E = 1 / 2 / 4 / 8
+// against k rounds of a six-step wave minimum (k = 20: 360 dependent cross-lane moves).  (value key, index) is a total order (the indices of a list are
+// distinct), so the first k places hold exactly what k pops of WaveList return, in the same order.
+template <int E>
+struct WaveSort {
+    unsigned long long key[E];
+    int i[E];
+    __device__ inline void load_and_sort(const double *__restrict__ cv, const int *__restrict__ ci, int c, int lane) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int t = lane + 64 * e;
+            key[e] = t < c ? topk_key(cv[t]) : ~0ull;
+            i[e] = t < c ? (ci ? ci[t] : t) : 0x7fffffff;
+        }
+#pragma unroll
+        for (int k = 2; k <= 64 * E; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64) {
+                    const int je = j >> 6;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & je) == 0) {
+                            const int f = e | je;
+                            const bool asc = ((64 * e) & k) == 0;          // (the direction bit of a place: lane bits are below k here)
+                            const bool sw = key[f] < key[e] || (key[f] == key[e] && i[f] < i[e]);      // f's entry is the smaller
+                            if (sw == asc) {
+                                const unsigned long long tk = key[e]; key[e] = key[f]; key[f] = tk;
+                                const int ti = i[e]; i[e] = i[f]; i[f] = ti;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const unsigned long long xk = __shfl_xor(key[e], j, 64);
+                        const int xi = __shfl_xor(i[e], j, 64);
+                        const int pl = 64 * e + lane;
+                        const bool lower = (lane & j) == 0, asc = (pl & k) == 0;
+                        const bool other_smaller = xk < key[e] || (xk == key[e] && xi < i[e]);
+                        // the lower place of an ascending pair keeps the smaller entry
+                        if ((lower == asc) == other_smaller) { key[e] = xk; i[e] = xi; }
+                    }
+                }
+            }
+    }
+};
+
+// the first k places of a sorted list -> out (values as doubles); place p sits in lane p % 64, slot p / 64
+template <int E>
+__device__ inline void wavesort_emit(const WaveSort<E> &ws, int k, int lane, double *__restrict__ ov, int *__restrict__ oi) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int pl = 64 * e + lane;
+        if (pl < k) { ov[pl] = topk_unkey(ws.key[e]); oi[pl] = ws.i[e]; }
+    }
+}
+
 // tau[row] = the (k+1)-th smallest of the row's M sampled distances, slightly inflated.  One wave per row, k + 1 rounds of
 // "next smallest" (k is small against M; a bitonic sort of the sample in LDS took 2.2 ms for 100 000 rows of 1024).
 // The row's own node may be among the sampled columns (its distance is an exact 0 and comes first): the (k+1)-th smallest
@@ -229,12 +288,12 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const int *__restrict_
     double last_v = -INFINITY;
     int last_i = -1;
     if (c <= 512) {
-        WaveList<8> wl;
-        wl.load(cv, ci, c, lane);
-        for (int q = 0; q < k; ++q) {
-            wl.pop(last_v, last_i);
-            if (lane == 0) { out_idx[lr * (int64_t)k + q] = last_i; out_val[lr * (int64_t)k + q] = last_v; }
-        }
+        double *ov = out_val + lr * (int64_t)k;
+        int *oi = out_idx + lr * (int64_t)k;
+        if (c <= 64) { WaveSort<1> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, ov, oi); }
+        else if (c <= 128) { WaveSort<2> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, ov, oi); }
+        else if (c <= 256) { WaveSort<4> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, ov, oi); }
+        else { WaveSort<8> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, ov, oi); }
         return;
     }
     for (int q = 0; q < k; ++q) {
@@ -261,12 +320,13 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(int *__restrict__ cnt
     double last_v = -INFINITY;
     int last_i = -1;
     if (c <= 512) {
-        WaveList<8> wl;
-        wl.load(cv, ci, c, lane);
-        for (int q = 0; q < k; ++q) {
-            wl.pop(last_v, last_i);
-            if (lane == 0) { sel_v[q] = last_v; sel_i[q] = last_i; }
-        }
+        // (k < c <= 512: sorted across the wave, the first k places into the LDS staging the copy below reads)
+        if (c <= 64) { WaveSort<1> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, sel_v, sel_i); }
+        else if (c <= 128) { WaveSort<2> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, sel_v, sel_i); }
+        else if (c <= 256) { WaveSort<4> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, sel_v, sel_i); }
+        else { WaveSort<8> ws; ws.load_and_sort(cv, ci, c, lane); wavesort_emit(ws, k, lane, sel_v, sel_i); }
+        __builtin_amdgcn_wave_barrier();
+        last_v = sel_v[k - 1];
     } else {
         for (int q = 0; q < k; ++q) {
             wave_lex_next(cv, ci, c, last_v, last_i, lane, last_v, last_i);
