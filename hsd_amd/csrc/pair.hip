@@ -745,7 +745,12 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 
     // this wave's share: XCD x (workgroups b, b + 8, ... share one) owns a contiguous run of the tile order
     const int x = blockIdx.x & 7, wx = blockIdx.x >> 3, nwx = gridDim.x >> 3;
-    const int q = a.ntiles >> 3, rr = a.ntiles & 7;
+    int ntiles = a.ntiles;
+    if constexpr (TOPK) {
+        // (pruned sweep: the launch's tile count comes from the filter kernel that ran just before on the same stream -- a scalar load)
+        if (a.ntiles_dev) ntiles = __builtin_amdgcn_readfirstlane(*a.ntiles_dev);
+    }
+    const int q = ntiles >> 3, rr = ntiles & 7;
     const int lo = x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q;
     const int hi = lo + (x < rr ? q + 1 : q);
     // the first three tiles of a workgroup are fixed (lo + wx, + nwx, + 2 nwx); from then on it draws the next free tile of
@@ -2099,12 +2104,19 @@ int launch_region(hsd_ctx *ctx, PairArgs a, int BT, hipStream_t stream, bool all
                     hipLaunchKernelGGL(tk_filter_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, l_in, n_in, a.prune_lo, a.prune_hi, a.prune_scale, a.prune_nf,
                                        a.prune_nt, ctx->d_tk_tmax, a.prune_drop_band, ti_off, tj_off, a.mirror ? 0 : 1, a.prune_band_lo, a.prune_band_hi,
                                        reinterpret_cast<int2 *>(ctx->d_tk_list), ctx->d_tk_count);
-                    if (e == hipSuccess) e = hipMemcpyAsync(&kept, ctx->d_tk_count, sizeof(int), hipMemcpyDeviceToHost, stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                    // The kernel reads the count the filter left in device memory (PairArgs::ntiles_dev): no host round trip between the launches
+                    // of a sweep.  The grid is sized for the unfiltered list (workgroups without a tile leave at once).  HSD_TOPK_VERBOSE still
+                    // fetches the count, to print it.
+                    kept = n_in;
+                    if (hsd_hook(H_TOPK_VERBOSE)) {
+                        if (e == hipSuccess) e = hipMemcpyAsync(&kept, ctx->d_tk_count, sizeof(int), hipMemcpyDeviceToHost, stream);
+                        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                        if (e == hipSuccess) fprintf(stderr, "[hsd topk] pruned launch: %d of %d tile pairs kept\n", kept, n_in);
+                    }
                     if (e != hipSuccess) return hsd_fail(ctx, HSD_ERR_HIP, "k-nearest tile filter: %s", hipGetErrorString(e));
-                    if (hsd_hook(H_TOPK_VERBOSE)) fprintf(stderr, "[hsd topk] pruned launch: %d of %d tile pairs kept\n", kept, n_in);
                     b.tiles = reinterpret_cast<const int2 *>(ctx->d_tk_list);
-                    b.ntiles = n_in = kept;
+                    b.ntiles = n_in;
+                    b.ntiles_dev = ctx->d_tk_count;
                 }
                 if (n_in > 0) {
                     if (a.tau)

@@ -102,6 +102,9 @@ struct PairArgs {
     // "not itself" is decided on the ORIGINAL ids (kernel: self_by_orig); the first launch paired row tile t with the column tiles
     // [prune_band_lo[t], prune_band_hi[t]], which the filter of the later launches drops (host side)
     int self_by_orig;
+    // pruned sweep: the number of tiles of THIS launch as the tile filter left it in device memory (k-nearest kernel only; nullptr: `ntiles` holds it).
+    // The host then need not wait for the count between two launches of a sweep (six blocking 4-byte copies per call before round 5).
+    const int *ntiles_dev;
     const int32_t *prune_band_lo, *prune_band_hi;
     const int32_t *gl_ov;           // host side only: the region's granule list and its per-tile maxima given by the caller (permuted operands)
     const uint32_t *tmax_ov;
