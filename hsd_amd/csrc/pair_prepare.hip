@@ -898,14 +898,23 @@ int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metr
                            hpart.as<double>(), lz.as<double>());
         hipLaunchKernelGGL(kl_logz_column_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, (const double *)lz.as<double>(), nl, npad, n,
                            (int64_t)nl * B + nl, sym, half, (double *)ctx->d_X, (double *)ctx->d_Y);
-        // occupancy masks per 16-node granule; the tile's column list lives in the kernel's chunk-list area as uint16 ids
+        // occupancy masks per 16-node granule; the tile's column list lives in the kernel's chunk-list area as uint16 ids.  Trimming only while two
+        // lists of a half's columns fit the persistent workgroup's LDS budget (two workgroups per CU: config 3 has 986 columns per half; ~1 700 is
+        // the limit) and the ids fit 16 bits, and the masks' words fit the planning wave's 64 lanes: otherwise the sparse columns are simply multiplied densely
         const int kwords = (half_alg + 63) / 64;
-        const int64_t ngran16 = npad / 16;
-        int rc_m;
-        if ((rc_m = hsd_op_alloc(ctx, &ctx->d_kl_mask, (size_t)ngran16 * kwords))) return rc_m;
-        hipLaunchKernelGGL(kl_mask_kernel, dim3((unsigned)((ngran16 * kwords + 255) / 256)), block, 0, ctx->stream, p, nl, kwords, ngran16, ctx->d_kl_mask);
-        ctx->kl_words = kwords;
-        ctx->list_cap = (half_alg * 2 + 7) / 8 + 2;              // int2 entries per list buffer: half_alg uint16 ids (+ slack for a whole last chunk)
+        const int list_cap = (half_alg * 2 + 7) / 8 + 2;        // int2 entries per list buffer: half_alg uint16 ids (+ slack for a whole last chunk)
+        // (launch_stream's sum for this kind: two stages of 2 x 16 fp64 columns x 128 nodes, the two lists, the plan ring and descriptions, the
+        //  entropy term and -- closed form of ring 0 -- the ring-0 values of two tiles, the k-nearest sweep's thresholds)
+        const size_t lds_two = 2 * ((size_t)65536 + (size_t)2 * list_cap * 8 + 16 + 3 * 24 * 4 + 32 + 4 * sizeof(HsdSegDesc) +
+                                    (size_t)2 * (ctx->has_point ? 2 : 1) * 256 * 8 + 512);
+        if (half_alg <= 65535 && kwords <= 64 && lds_two <= (size_t)160 * 1024 && hsd_hook_int(H_KL_TRIM, 1) != 2) {      // (HSD_KL_TRIM=2: tests)
+            const int64_t ngran16 = npad / 16;
+            int rc_m;
+            if ((rc_m = hsd_op_alloc(ctx, &ctx->d_kl_mask, (size_t)ngran16 * kwords))) return rc_m;
+            hipLaunchKernelGGL(kl_mask_kernel, dim3((unsigned)((ngran16 * kwords + 255) / 256)), block, 0, ctx->stream, p, nl, kwords, ngran16, ctx->d_kl_mask);
+            ctx->kl_words = kwords;
+            ctx->list_cap = list_cap;
+        }
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (lz goes)
     }
     hipLaunchKernelGGL(sum_layers_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, hpart.as<double>(), nl, npad, n, ctx->d_H);

@@ -547,6 +547,9 @@ def test_kl_sparse_columns_and_tile_trimming(engine, n, p, K):
             trimmed, cols, work = run("1")
             one_tile, _, _ = run("0")
             assert np.array_equal(trimmed, one_tile), (metric, alpha, srt)
+            # the same persistent kernel over every column (HSD_KL_TRIM=2: what a hierarchy too deep for the column lists' LDS budget gets)
+            untrimmed, ucols, uwork = _with_env("HSD_KL_TRIM", "2", lambda: run("1"))
+            assert np.array_equal(trimmed, untrimmed) and ucols == cols and uwork >= work
             if p is None:
                 assert work < 0.99 * cols, (work, cols)                     # columns were skipped (3 % at this size; 27 % at config 3: outer rings of a large graph hold few hubs)
             dense, dcols, dwork = _with_env("HSD_KL_TRIM", "0", lambda: run("1"))
