@@ -143,10 +143,11 @@ def test_bench_line_contract_two_ranks(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSD_COMM_DRYRUN="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (--configs 4: the branch `--gpus 8` takes by default -- config 4 on the same ranks, a fresh context -- rehearsed on a stand-in graph of 24 000 nodes)
+    env = dict(os.environ, HSD_COMM_DRYRUN="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HSD_BENCH_CONFIG4_NODES="24000")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--graph", "ba", "--nodes", "20000", "--cpu-seconds", "1.5",
-                        "--configs", "none", "--detail", "bench_detail_contract_test2.json"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+                        "--configs", "4", "--detail", "bench_detail_contract_test2.json"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     d, detail = _check_contract_line(p.stdout, 2, 3, 1)
     assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("row-block x2") and "rehearsal" in d["data"]
@@ -155,6 +156,11 @@ def test_bench_line_contract_two_ranks(tmp_path):
     assert d["design_ceiling"]["speedup_at_most"] == 1.33
     assert d["fused_knn"]["exact"] is True and d["fused_knn"]["ms_end_to_end"] > 0 and len(detail["fused_knn"]["ms_per_rank"]) == 2
     assert d["parity"]["pairs_checked"] > 0                       # rank 0's rows of the CPU sample
+    (c4,) = d["configs"]
+    assert c4["config"] == "configs[3]" and "error" not in c4 and c4["variant"] == "B" and c4["value"] > 0
+    (full4,) = detail["configs"]
+    assert "REHEARSAL at N=24000" in full4["workload"] and [v["variant"] for v in full4["variants"]] == ["B", "A"]
+    assert all(len(v["kernel_ms_per_rank"]) == 2 and v["fused_knn"]["exact"] for v in full4["variants"])
 
 
 def test_single_node_structure_and_index_maps(engine, capsys):
