@@ -136,6 +136,35 @@ def test_kl_golden(engine, name):
     assert np.allclose(Ds[iu], Gs[iu], rtol=RTOL, atol=ATOL)
 
 
+KLM = np.load(os.path.join(GOLDEN, "kl_midsize.npz"))
+
+
+@pytest.mark.parametrize("name", ["usa", "cora"])
+@pytest.mark.parametrize("stream", ["0", "1"])
+def test_kl_golden_midsize(engine, name, stream):
+    """tests/golden/generate_golden_kl_midsize.py: the reference's own KL_divergence / calculate_distance on sampled pairs and whole
+    matrix rows of mid-size graphs -- sizes where the sparse-column form trims columns per tile (usa: 144 bins) -- through both kernels."""
+    g = _graph(name)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    pr, rows = KLM[f"{name}/pairs"], KLM[f"{name}/rows"]
+    fwd = pr[:, 0] < pr[:, 1]                              # the matrix holds KL(P_i || P_j) for i < j and its mirror below (model/HSD.py:132-134)
+
+    def run(kind, sort):
+        engine.pair_prepare(kind, 0, 0, 3, 0.5, sort)
+        return engine.pair_rows_host()
+
+    D = _with_env("HSD_STREAM", stream, lambda: run(1, False))
+    assert fwd.sum() > 200 and np.allclose(D[pr[fwd, 0], pr[fwd, 1]], KLM[f"{name}/KL"][fwd], rtol=RTOL, atol=ATOL)
+    assert np.allclose(D[rows], KLM[f"{name}/rows_KL"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(D, D.T)
+    S = _with_env("HSD_STREAM", stream, lambda: run(2, False))
+    assert np.allclose(S[pr[:, 0], pr[:, 1]], KLM[f"{name}/SKL"], rtol=RTOL, atol=ATOL)
+    assert np.allclose(S[rows], KLM[f"{name}/rows_SKL"], rtol=RTOL, atol=ATOL)
+    Ds = _with_env("HSD_STREAM", stream, lambda: run(1, True))
+    assert np.allclose(Ds[pr[fwd, 0], pr[fwd, 1]], KLM[f"{name}/KLsorted"][fwd], rtol=RTOL, atol=ATOL)
+
+
 def _with_env(name, value, fn):
     old = os.environ.get(name)
     os.environ[name] = value

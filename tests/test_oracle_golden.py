@@ -140,6 +140,21 @@ def test_degree_kl_c_oracle(name):
     assert np.allclose(SKL, D[f"{name}/SKL_a0.5"], rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("name", ["usa", "cora"])
+def test_degree_kl_midsize_c_oracle(name):
+    """tests/golden/generate_golden_kl_midsize.py: the reference's KL_divergence on sampled pairs and whole rows of mid-size graphs."""
+    M = np.load(os.path.join(GOLDEN, "kl_midsize.npz"))
+    g = load_graph(name)
+    rings = orc.khop_rings(g.rowptr, g.col, 3)
+    _, counts = orc.degree_histograms(g.degree, rings, 4)
+    assert counts.shape[2] == int(M[f"{name}/bins"][0])
+    rows = M[f"{name}/rows"]
+    for sym, key in ((False, "rows_KL"), (True, "rows_SKL")):
+        for a, i in enumerate(rows):
+            got = corc.pair_rows_kl(counts, 0, 3, 0.5, sym, int(i), int(i) + 1)[0]
+            assert np.allclose(got, M[f"{name}/{key}"][a], rtol=1e-12, atol=1e-14)
+
+
 def test_robust_csv_known_answer():
     """tests/robust_test/robust.csv: BFS + exact heat kernel + threshold + ring sum/mean/var."""
     R = np.load(os.path.join(GOLDEN, "robust_kat.npz"))
