@@ -2373,6 +2373,7 @@ extern "C" int hsd_pair_rows(hsd_ctx *ctx, int64_t r0, int64_t r1, double *out, 
         b.ld = dld;
         b.rbase = rb;
         b.i_begin = ra; b.i_end = re;
+        if (rb != 0) b.dbg &= ~16;      // (measurement hook "no HBM write stream" aims every tile at rows 0..255 of a matrix that starts at node 0: not for a row block)
         int rc;
         // The diagonal square (symmetric) and the rectangles left and right of it write disjoint parts of the
         // row block: a multi-GPU rank has all three, and they run side by side (two side streams forked from

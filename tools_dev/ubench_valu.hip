@@ -32,7 +32,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void bench(uint32_t *sink, Stamp *stamps, uint32_t seed) {
     const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
     uint32_t a32[16], b32[16], c32[16];
-    double a64[16], b64[16], tmp64;
+    double a64[16], b64[16], tmp64, tmp64b;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         a32[i] = (t * 2654435761u + i * 40503u + seed) | 1u;
@@ -146,6 +146,30 @@ __global__ __launch_bounds__(256) void bench(uint32_t *sink, Stamp *stamps, uint
 #define M(i) asm volatile("v_add_f64 %1, %2, -%3\n\tv_add_f64 %0, %0, |%1|" : "+v"(a64[i]), "=&v"(tmp64) : "v"(b64[i & 3]), "v"(b64[4 + (i >> 2)]));
                 REP16(M)
 #undef M
+            } else if constexpr (KIND == 25) {  // v_cvt_f64_u32 (the fold's conversion of an integer sum)
+#define M(i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a64[i]) : "v"(c32[i]));
+                REP16(M)
+#undef M
+            } else if constexpr (KIND == 26) {  // v_min_f64
+#define M(i) asm volatile("v_min_f64 %0, %0, %1" : "+v"(a64[i]) : "v"(b64[i]));
+                REP16(M)
+#undef M
+            } else if constexpr (KIND == 27) {  // v_swap_b32 (the mirrored tile's exchange)
+#define M(i) asm volatile("v_swap_b32 %0, %1" : "+v"(c32[i]), "+v"(a32[i]));
+                REP16(M)
+#undef M
+            } else if constexpr (KIND == 28) {  // v_mov_b32 (zeroing an integer sum)
+#define M(i) asm volatile("v_mov_b32 %0, %1" : "=v"(c32[i]) : "v"(a32[i]));
+                REP16(M)
+#undef M
+            } else if constexpr (KIND == 29) {  // one pair of a layer's fold: cvt, min, fma, zero
+#define M(i) asm volatile("v_cvt_f64_u32 %2, %1\n\tv_min_f64 %3, %4, %5\n\tv_fmac_f64 %0, %2, %3\n\tv_mov_b32 %1, 0" : "+v"(a64[i]), "+v"(c32[i]), "=&v"(tmp64), "=&v"(tmp64b) : "v"(b64[i & 3]), "v"(b64[4 + (i >> 2)]));
+                REP16(M)
+#undef M
+            } else if constexpr (KIND == 30) {  // v_cvt_f64_u32 between SADs: does the conversion hold the integer pipe?
+#define M(i) asm volatile("v_cvt_f64_u32 %0, %1\n\tv_sad_u16 %1, %2, %3, %1\n\tv_sad_u16 %2, %1, %3, %2\n\tv_sad_u16 %3, %1, %2, %3" : "=v"(a64[i]), "+v"(c32[i]), "+v"(a32[i]), "+v"(b32[i]));
+                REP16(M)
+#undef M
             }
         }
     }
@@ -185,6 +209,8 @@ int main(int argc, char **argv) {
         {"v_qsad_pk_u16_u8", bench<16>, 1}, {"v_mqsad_pk_u16_u8", bench<17>, 1}, {"v_add_f64 + v_sad_u16 alternating", bench<18>, 2},
         {"v_dot4_u32_u8", bench<19>, 1}, {"v_pk_add_u16", bench<20>, 1}, {"v_sub_u32 + v_max_i32", bench<21>, 2}, {"v_min_u32", bench<22>, 1},
         {"v_sad_u16 (4x4 operand reuse)", bench<23>, 1}, {"v_add_f64 sub + v_add_f64 |acc| (W1 fp64 pair)", bench<24>, 2},
+        {"v_cvt_f64_u32", bench<25>, 1}, {"v_min_f64", bench<26>, 1}, {"v_swap_b32", bench<27>, 1}, {"v_mov_b32", bench<28>, 1},
+        {"fold of one pair: cvt + min + fmac + mov 0", bench<29>, 4}, {"v_cvt_f64_u32 + 3 v_sad_u16", bench<30>, 4},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
