@@ -992,7 +992,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
     unsigned long long work = 0;
     bool first_landed = false;
 #if HSD_STAMPS
-    unsigned long long cyc_store = 0, cyc_loop = 0, cyc_epi = 0, n_tiles = 0;      // HSD_DEBUG bit 3 only
+    unsigned long long cyc_store = 0, cyc_loop = 0, cyc_epi = 0, n_tiles = 0, cyc_wait = 0, cyc_bar = 0;      // HSD_DEBUG bit 3 only
 #endif
 
     // DEFERRED STORES (integer kinds, matrix output).  A finished tile's 64 result stores per wave do not leave in one burst
@@ -1244,8 +1244,17 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
             // (the first chunk of a tile was waited for before the previous tile's stores went out)
             // (... and then the barrier at the top of the tile has already told every wave so: no second one)
             if (!(k == 0 && first_landed)) {
+#if HSD_STAMPS
+                const unsigned long long c_w0 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
                 wait_vm_young(__builtin_amdgcn_readfirstlane(vm_seq - (st ? seq_of_stage[1] : seq_of_stage[0])));
+#if HSD_STAMPS
+                const unsigned long long c_w1 = (a.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
                 wg_barrier();                         // every wave's part of chunk k has landed, and chunk k - 1 is consumed
+#if HSD_STAMPS
+                if (a.dbg & 8) { const unsigned long long c_w2 = __builtin_amdgcn_s_memtime(); cyc_wait += c_w1 - c_w0; cyc_bar += c_w2 - c_w1; }
+#endif
             }
             if constexpr (EARLY) {
                 if (dead) cvalid = 0;
@@ -1668,10 +1677,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pair_stream_kernel(const PairArgs 
 #if HSD_STAMPS
     if ((a.dbg & 8) && a.stamps && threadIdx.x == 0) {
         // measurement hook: (start, end) of this workgroup in 100 MHz ticks
-        unsigned long long *sp = a.stamps + 6 * (size_t)blockIdx.x;
+        unsigned long long *sp = a.stamps + 8 * (size_t)blockIdx.x;
         sp[0] = stamp0;
         sp[1] = __builtin_amdgcn_s_memrealtime();
-        sp[2] = cyc_loop; sp[3] = cyc_epi; sp[4] = cyc_store; sp[5] = n_tiles;
+        sp[2] = cyc_loop; sp[3] = cyc_epi; sp[4] = cyc_store; sp[5] = n_tiles; sp[6] = cyc_wait; sp[7] = cyc_bar;
     }
 #endif
 }
@@ -1833,14 +1842,14 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
         // HSD_DEBUG bit 3: per-workgroup lifetimes -> stderr (synchronises; measurement only; its own buffer)
         PairArgs b = a;
         unsigned long long *d_st = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&d_st), (size_t)grid * 48) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemset(d_st, 0, (size_t)grid * 48);
+        if (hipMalloc(reinterpret_cast<void **>(&d_st), (size_t)grid * 64) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d_st, 0, (size_t)grid * 64);
         b.stamps = d_st;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, b);
         (void)hipStreamSynchronize(stream);
-        std::vector<unsigned long long> h6((size_t)grid * 6), h((size_t)grid * 2);
+        std::vector<unsigned long long> h6((size_t)grid * 8), h((size_t)grid * 2);
         (void)hipMemcpy(h6.data(), d_st, h6.size() * 8, hipMemcpyDeviceToHost);
-        for (int g = 0; g < grid; ++g) { h[2 * g] = h6[6 * g]; h[2 * g + 1] = h6[6 * g + 1]; }
+        for (int g = 0; g < grid; ++g) { h[2 * g] = h6[8 * g]; h[2 * g + 1] = h6[8 * g + 1]; }
         (void)hipFree(d_st);
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int g = 0; g < grid; ++g) if (h[2 * g]) { t0 = std::min(t0, h[2 * g]); t1 = std::max(t1, h[2 * g + 1]); }
@@ -1854,9 +1863,13 @@ hipError_t launch_stream(hsd_ctx *ctx, const PairArgs &a, hipStream_t stream) {
         fprintf(stderr, "[hsd stream<%d,%d>] %zu workgroups, span %.1f us; end times us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f; mean end per b%%8:", KIND, NW,
                 endt.size(), (t1 - t0) * 1e-2, endt.front(), endt[endt.size() / 10], endt[endt.size() / 2], endt[endt.size() * 9 / 10], endt.back());
         for (int x8 = 0; x8 < 8; ++x8) fprintf(stderr, " %.0f", cnt[x8] ? per_xcd[x8] / cnt[x8] : 0.0);
-        double cl = 0, ce = 0, cs = 0, nt = 0;
-        for (int g = 0; g < grid; ++g) { cl += (double)h6[6 * g + 2]; ce += (double)h6[6 * g + 3]; cs += (double)h6[6 * g + 4]; nt += (double)h6[6 * g + 5]; }
-        if (nt > 0) fprintf(stderr, "; wave-0 cycles per tile: chunk loop %.0f, fold + next-tile requests %.0f, stores %.0f (%.0f tiles)", cl / nt, ce / nt, cs / nt, nt);
+        double cl = 0, ce = 0, cs = 0, nt = 0, cw = 0, cb = 0;
+        for (int g = 0; g < grid; ++g) {
+            cl += (double)h6[8 * g + 2]; ce += (double)h6[8 * g + 3]; cs += (double)h6[8 * g + 4]; nt += (double)h6[8 * g + 5];
+            cw += (double)h6[8 * g + 6]; cb += (double)h6[8 * g + 7];
+        }
+        if (nt > 0) fprintf(stderr, "; wave-0 cycles per tile: chunk loop %.0f (of which waiting for a chunk's loads -- in-order behind older stores -- %.0f, at the chunk barrier %.0f), "
+                            "fold + next-tile requests %.0f, stores %.0f (%.0f tiles)", cl / nt, cw / nt, cb / nt, ce / nt, cs / nt, nt);
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
