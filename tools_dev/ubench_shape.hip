@@ -22,7 +22,7 @@ __device__ inline void gstore16_s(uint64_t sbase, uint32_t lane_off, v2f64 val) 
 }
 
 // flags: 1 no stores, 2 no arithmetic
-template <int TC, int OCC>
+template <int TC, int OCC, int STAG>
 __global__ __launch_bounds__(256, OCC) void shape_kernel(double *out, int64_t ld, const int2 *__restrict__ tiles, int ntiles, int words, int flags,
                                                          const uint32_t *__restrict__ seed) {
     constexpr int TR = 8, BI = 128, BJ = 16 * TC;           // tile: 128 rows x (128 | 64) columns
@@ -94,16 +94,28 @@ __global__ __launch_bounds__(256, OCC) void shape_kernel(double *out, int64_t ld
         const int ti = __builtin_amdgcn_readfirstlane(tt.x), tj = __builtin_amdgcn_readfirstlane(tt.y);
         const bool mirror = (int64_t)BJ * tj >= (int64_t)BI * (ti + 1);      // strictly above the diagonal square: also written mirrored
         for (int c0 = 0; c0 < words; c0 += 8) {
-            __syncthreads();                                 // (the chunk barrier)
-            if (pend_g < NG) {
-                if (pend_g == NGD && pend_mirror) transpose_acc();
-                store_group(pend_g, pend_ti, pend_tj, pend_mirror);
-                ++pend_g;
+            if (STAG != 2) __syncthreads();                  // (the chunk barrier; STAG == 2: none -- how much do the barriers' lock-step cost?)
+            if (STAG != 1 || (flags & 2)) {
+                if (pend_g < NG) {
+                    if (pend_g == NGD && pend_mirror) transpose_acc();
+                    store_group(pend_g, pend_ti, pend_tj, pend_mirror);
+                    ++pend_g;
+                }
             }
             if (!(flags & 2)) {
                 const int nw = min(8, words - c0);
 #pragma unroll 1
                 for (int u = 0; u < nw; u += 2) {
+                    if (STAG == 1 && (u == 2 * w || (u == 0 && 2 * w >= nw))) {
+                        // STAGGERED: the four waves of a workgroup leave the barrier together; with the group in front of the trip all four
+                        // (one per SIMD) queue their eight stores at the CU's store path at once and each waits for everybody's.  Here wave w
+                        // issues its group in front of word 2 w of the trip.
+                        if (pend_g < NG) {
+                            if (pend_g == NGD && pend_mirror) transpose_acc();
+                            store_group(pend_g, pend_ti, pend_tj, pend_mirror);
+                            ++pend_g;
+                        }
+                    }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int c = (c0 + u + h) & 15;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256, OCC) void shape_kernel(double *out, int64_t ld
     }
 }
 
-template <int TC, int OCC>
+template <int TC, int OCC, int STAG>
 static void run(const char *name, double *out, int64_t n, int words, const uint32_t *seed, int cus) {
     constexpr int BJ = 16 * TC;
     std::vector<int2> tiles;
@@ -161,7 +173,7 @@ static void run(const char *name, double *out, int64_t n, int words, const uint3
     int2 *d_tiles;
     CHECK(hipMalloc(&d_tiles, tiles.size() * sizeof(int2)));
     CHECK(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
-    auto kern = shape_kernel<TC, OCC>;
+    auto kern = shape_kernel<TC, OCC, STAG>;
     const size_t lds = (size_t)(160 * 1024 / OCC) / 1024 * 1024 - 1024;     // pins OCC workgroups per CU
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = cus * OCC;
@@ -200,9 +212,13 @@ int main(int argc, char **argv) {
     CHECK(hipMemcpy(seed, h.data(), 4096 * 4, hipMemcpyHostToDevice));
     printf("device %s, %d CUs, n = %lld (%.1f GB of output), %d words per pair\n", prop.gcnArchName, prop.multiProcessorCount, (long long)n, (double)n * n * 8 / 1e9, words);
     CHECK(hipMemset(out, 0, (size_t)n * n * 8));
-    run<8, 2>("128 x 128 tiles, 8 x 8 per lane, 2 WG / CU", out, n, words, seed, prop.multiProcessorCount);
-    run<4, 3>("128 x 64 tiles, 8 x 4 per lane, 3 WG / CU", out, n, words, seed, prop.multiProcessorCount);
-    run<4, 2>("128 x 64 tiles, 8 x 4 per lane, 2 WG / CU", out, n, words, seed, prop.multiProcessorCount);
-    run<4, 4>("128 x 64 tiles, 8 x 4 per lane, 4 WG / CU", out, n, words, seed, prop.multiProcessorCount);
+    run<8, 2, 0>("128x128, 8x8/lane, 2 WG/CU", out, n, words, seed, prop.multiProcessorCount);
+    run<8, 2, 1>("128x128, 8x8/lane, 2 WG/CU, staggered groups", out, n, words, seed, prop.multiProcessorCount);
+    run<8, 2, 2>("128x128, 8x8/lane, 2 WG/CU, no chunk barriers", out, n, words, seed, prop.multiProcessorCount);
+    run<4, 3, 0>("128x64, 8x4/lane, 3 WG/CU", out, n, words, seed, prop.multiProcessorCount);
+    run<4, 3, 1>("128x64, 8x4/lane, 3 WG/CU, staggered groups", out, n, words, seed, prop.multiProcessorCount);
+    run<4, 3, 2>("128x64, 8x4/lane, 3 WG/CU, no chunk barriers", out, n, words, seed, prop.multiProcessorCount);
+    run<4, 4, 0>("128x64, 8x4/lane, 4 WG/CU", out, n, words, seed, prop.multiProcessorCount);
+    run<4, 4, 1>("128x64, 8x4/lane, 4 WG/CU, staggered groups", out, n, words, seed, prop.multiProcessorCount);
     return 0;
 }
