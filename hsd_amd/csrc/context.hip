@@ -51,6 +51,7 @@ const HsdHookInfo hsd_hook_table[H_COUNT] = {
     {"HSD_SHARD_BALANCE", "0 = hsd_pair_shard returns blocks of equal height whatever the kind"},
     {"HSD_KL_POINT", "KL kinds: 0 = layer 0 (ring 0 = the node itself) stays in the dense loop instead of its closed form; read at prepare time"},
     {"HSD_KL_TRIM", "KL kinds: 0 = the dense form (P . log P over every column) instead of the sparse-column form with per-tile column trimming, 2 = the sparse columns multiplied without trimming (what a hierarchy too deep for the column lists' LDS gets); read at prepare time"},
+    {"HSD_PREP_STAGED", "0 = the operand-preparation kernels read each node's histogram row in place (one thread per node) instead of staging the rows of 64 nodes in LDS with coalesced loads first; same operands either way"},
     {"HSD_DEBUG", "(-DHSD_DEBUG_HOOKS builds only: `make debug`) ablation bits of the pair kernels: 1 no stores, 2 no arithmetic, 16 stores stay in L2; 4 / 8 only in -DHSD_STAMPS builds"},
     {"HSD_SIDE_STREAMS", "0 = the three regions of a row block in sequence instead of side by side (three-launch form only)"},
     {"HSD_TOPK_DEBUG", "(-DHSD_DEBUG_HOOKS builds only) fused k-nearest consumer: 1 = sweep without its candidate epilogue (timing only: the call then fails); 32 = pruned sweep without the early exit of finished waves (A/B)"},

@@ -40,6 +40,7 @@ enum HsdHook {
     H_SHARD_BALANCE,
     H_KL_POINT,
     H_KL_TRIM,
+    H_PREP_STAGED,
     H_DEBUG,
     H_SIDE_STREAMS,
     H_TOPK_DEBUG,

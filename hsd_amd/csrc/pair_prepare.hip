@@ -30,27 +30,87 @@ struct PrepArgs {
     int L, B;                   // layers in the counts tensor, bins
     int layer_lo, layer_hi;
     int *flag;                  // flag[0] |= 1 : empty ring met
+    int stage_nodes;            // 0: one thread per node reads its row of `counts` from memory; else: workgroups of 256 threads stage the rows of
+                                // stage_nodes (<= 64) consecutive nodes in LDS first (counts_row)
 };
+
+// The histogram row of (node i, layer k) for the thread that walks it, and i.  A row is B consecutive words, a node's rows are L x B words apart: with one
+// thread per node reading its row in place every load of a wave touches 64 different lines (0.59 / 0.63 / 0.34 ms for the three walks of a zero-pad
+// prepare at BA N = 100k, B = 241: the 193 MB of two layers were fetched ~20 times over).  Staged launches (PrepArgs::stage_nodes, prep_launch_geometry) copy the
+// rows of their nodes into LDS first -- four waves, 32 row-coalesced loads in flight per lane, odd row stride: no bank conflicts -- and threads 0 ..
+// stage_nodes - 1 then walk row t out of LDS; the other threads leave behind the barrier.  nullptr: nothing to do for this thread.
+// (the node of this thread without its row: launches whose layer needs none, e.g. ring 0)
+__device__ inline bool node_of_thread(const PrepArgs &p, int64_t &i) {
+    if (p.stage_nodes == 0) i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    else i = (int)threadIdx.x < p.stage_nodes ? (int64_t)blockIdx.x * p.stage_nodes + threadIdx.x : p.n;
+    return i < p.n;
+}
+__device__ inline const uint32_t *counts_row(const PrepArgs &p, int k, int64_t &i) {
+    if (p.stage_nodes == 0) {
+        i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        return i < p.n ? p.counts + (i * p.L + k) * p.B : nullptr;
+    }
+    extern __shared__ uint32_t prep_rows[];
+    const int stride = p.B | 1;
+    const int64_t i0 = (int64_t)blockIdx.x * p.stage_nodes;
+    const int nodes = (int)min((int64_t)p.stage_nodes, p.n - i0);
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, nw = (int)blockDim.x >> 6;
+    // (16 rows x 2 words per lane in flight: with 8 x 1 the copy ran at 1.2 TB/s -- 16 KB in flight per CU against a ~3 us round trip)
+    for (int t0 = w; t0 < nodes; t0 += 16 * nw) {
+        for (int b = lane; b < p.B; b += 128) {
+            uint32_t v[16][2];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int t = t0 + u * nw;
+                const uint32_t *src = p.counts + ((i0 + t) * p.L + k) * p.B;
+                v[u][0] = t < nodes ? src[b] : 0u;
+                v[u][1] = (t < nodes && b + 64 < p.B) ? src[b + 64] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int t = t0 + u * nw;
+                if (t < nodes) {
+                    prep_rows[t * stride + b] = v[u][0];
+                    if (b + 64 < p.B) prep_rows[t * stride + b + 64] = v[u][1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    i = i0 + threadIdx.x;
+    return (int)threadIdx.x < nodes ? prep_rows + (int)threadIdx.x * stride : nullptr;
+}
+
+// launch shape of a kernel that walks histogram rows through counts_row: (grid, block, dynamic LDS) for `ny` layers
+struct PrepGeom { dim3 grid, block; size_t lds; };
+static PrepGeom prep_launch_geometry(const PrepArgs &p, int ny) {
+    if (p.stage_nodes > 0)
+        return PrepGeom{dim3((unsigned)((p.n + p.stage_nodes - 1) / p.stage_nodes), (unsigned)ny), dim3(256), (size_t)p.stage_nodes * (size_t)(p.B | 1) * sizeof(uint32_t)};
+    return PrepGeom{dim3((unsigned)((p.n + 255) / 256), (unsigned)ny), dim3(256), 0};
+}
 
 // W1 raw samples: column block of layer k>=1 holds G[b] = (cc[b]/n) * (s[b+1]-s[b]), b < B-1.
 // One thread per (node, layer).
 __global__ void prep_l1_kernel(PrepArgs p, double *__restrict__ X, int col_begin_first, int cols_per_layer,
                                double *__restrict__ point) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int k = p.layer_lo + blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
-    if (k == 0) {               // ring 0 = {i}: W1 of two point masses = |v_i - v_j|
+    int64_t i;
+    if (k == 0) {
+        if (!node_of_thread(p, i)) return;               // ring 0 = {i}: W1 of two point masses = |v_i - v_j|
         point[i] = p.support[p.node_bin[i]];
         return;
     }
+    const uint32_t *c = counts_row(p, k, i);
+    if (!c) return;
     uint32_t tot = 0;
+    #pragma unroll 8
     for (int b = 0; b < p.B; ++b) tot += c[b];
     if (tot == 0) atomicOr(p.flag, 1);
     const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
     const int64_t cb = col_begin_first + (int64_t)(k - first) * cols_per_layer;
     const double nn = (double)tot;
     uint32_t cc = 0;
+#pragma unroll 4
     for (int b = 0; b + 1 < p.B; ++b) {
         cc += c[b];
         const double cdf = tot ? (double)cc / nn : 0.0;
@@ -65,23 +125,26 @@ __global__ void prep_l1_kernel(PrepArgs p, double *__restrict__ X, int col_begin
 template <typename T>
 __global__ void prep_zp_kernel(PrepArgs p, T *__restrict__ X, double *__restrict__ inv, double *__restrict__ point,
                                const int *__restrict__ seg_begin, uint32_t *__restrict__ ntot /* [n_seg][npad] ring sizes */) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int k = p.layer_lo + blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
+    int64_t i;
     if (k == 0) {
+        if (!node_of_thread(p, i)) return;
         point[i] = p.support[p.node_bin[i]];
         return;
     }
+    const uint32_t *c = counts_row(p, k, i);
+    if (!c) return;
     const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
     const int s = k - first;
     uint32_t tot = 0;
+    #pragma unroll 8
     for (int b = 0; b < p.B; ++b) tot += c[b];
     inv[(int64_t)s * p.npad + i] = tot ? 1.0 / (double)tot : 2.0;
     ntot[(int64_t)s * p.npad + i] = tot;
     const int64_t cb = seg_begin[s];
     X[cb * p.npad + i] = (T)((double)tot * p.support[0]);
     uint32_t tail = tot;
+#pragma unroll 4
     for (int b = 0; b + 1 < p.B; ++b) {
         tail -= c[b];
         X[(cb + 1 + b) * p.npad + i] = (T)((double)tail * (p.support[b + 1] - p.support[b]));
@@ -96,12 +159,13 @@ template <bool PACK>
 __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_col0, const int *__restrict__ seg_rank_cap,
                                  const int *__restrict__ seg_first_bin, const int *__restrict__ seg_suf_row0, uint32_t *__restrict__ X,
                                  uint32_t *__restrict__ SUF) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
     const int sgi = blockIdx.y;
     const int k = first + sgi;
-    if (i >= p.n || seg_rank_col0[sgi] < 0) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
+    if (seg_rank_col0[sgi] < 0) return;                  // (the whole launch row: no thread reaches the barrier of counts_row)
+    int64_t i;
+    const uint32_t *c = counts_row(p, k, i);
+    if (!c) return;
     const int cap = seg_rank_cap[sgi], fb = seg_first_bin[sgi];
     const uint32_t theta = fb > 0 ? (uint32_t)p.support[fb - 1] : 0u;
     uint32_t *col = X + (int64_t)seg_rank_col0[sgi] * p.npad + i;
@@ -109,21 +173,31 @@ __global__ void prep_rank_kernel(PrepArgs p, const int *__restrict__ seg_rank_co
     // whole sum above theta minus what the first w words hold -- also where the rank columns themselves are cut off at the cap
     uint32_t *suf = SUF + (int64_t)seg_suf_row0[sgi] * p.npad + i;
     uint32_t total = 0;
+    #pragma unroll 8
     for (int b = p.B - 1; b >= fb; --b) total += c[b] * ((uint32_t)p.support[b] - theta);
     const int want = PACK ? 2 * cap : cap;           // values to emit
     int r = 0;
     uint32_t lo = 0, prefix = 0;
     suf[0] = total;
-    for (int b = p.B - 1; b >= fb && r < want; --b) {
-        const uint32_t v = (uint32_t)p.support[b] - theta;
-        for (uint32_t m = c[b]; m > 0 && r < want; --m, ++r) {
-            prefix += v;
-            if (PACK) {
-                if (r & 1) { col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16); suf[(int64_t)((r >> 1) + 1) * p.npad] = total - prefix; }
-                else lo = v;
-            } else {
-                col[(int64_t)r * p.npad] = v;
-                suf[(int64_t)(r + 1) * p.npad] = total - prefix;
+    // (eight bins' counts are read together: most bins of a node are empty, and one LDS / memory latency per empty bin was most of this kernel)
+    for (int b0 = p.B - 1; b0 >= fb && r < want; b0 -= 8) {
+        uint32_t cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = b0 - u >= fb ? c[b0 - u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (cc[u] == 0u) continue;
+            const int b = b0 - u;
+            const uint32_t v = (uint32_t)p.support[b] - theta;
+            for (uint32_t m = cc[u]; m > 0 && r < want; --m, ++r) {
+                prefix += v;
+                if (PACK) {
+                    if (r & 1) { col[(int64_t)(r >> 1) * p.npad] = lo | (v << 16); suf[(int64_t)((r >> 1) + 1) * p.npad] = total - prefix; }
+                    else lo = v;
+                } else {
+                    col[(int64_t)r * p.npad] = v;
+                    suf[(int64_t)(r + 1) * p.npad] = total - prefix;
+                }
             }
         }
     }
@@ -148,18 +222,21 @@ __global__ void pack_u8_kernel(uint32_t *__restrict__ X, int64_t npad, int src_c
 
 // above[(s * n_cand + q) * npad + i] = members of ring layer s of node i with bin index >= cand_bin[q]
 __global__ void count_above_kernel(PrepArgs p, const int *__restrict__ cand_bin, int n_cand, uint32_t *__restrict__ above) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int first = p.layer_lo == 0 ? 1 : p.layer_lo;
     const int sgi = blockIdx.y;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + first + sgi) * p.B;
+    int64_t i;
+    const uint32_t *c = counts_row(p, first + sgi, i);
+    if (!c) return;
+    // candidates ascend: from the top bin down, the bins between two candidates are one straight run of additions
     uint32_t run = 0;
-    int q = n_cand - 1;
-    for (int b = p.B - 1; b >= 0; --b) {
-        while (q >= 0 && cand_bin[q] > b) { above[((int64_t)sgi * n_cand + q) * p.npad + i] = run; --q; }
-        run += c[b];
+    int hi = p.B;
+    for (int q = n_cand - 1; q >= 0; --q) {
+        const int lo = min(cand_bin[q], hi);
+#pragma unroll 8
+        for (int b = hi - 1; b >= lo; --b) run += c[b];
+        hi = lo;
+        above[((int64_t)sgi * n_cand + q) * p.npad + i] = run;
     }
-    for (; q >= 0; --q) above[((int64_t)sgi * n_cand + q) * p.npad + i] = run;
 }
 
 // rmax[s][g] = largest ring size of layer segment s within the 64-node granule g
@@ -173,16 +250,18 @@ __global__ void granule_max_kernel(const uint32_t *__restrict__ ntot, int64_t np
 // KL: P = (c + alpha) / (n + alpha B), LP = log P, H = sum P LP.  symmetric: X = [P ; LP], Y = [LP ; P].
 __global__ void prep_kl_kernel(PrepArgs p, double alpha, int symmetric, int half_cols /* padded cols of one [P] block */,
                                double *__restrict__ X, double *__restrict__ Y, double *__restrict__ Hpart /* [nl][npad] */) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int kk = blockIdx.y;
     const int k = p.layer_lo + kk;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
+    int64_t i;
+    const uint32_t *c = counts_row(p, k, i);
+    if (!c) return;
     uint32_t tot = 0;
+    #pragma unroll 8
     for (int b = 0; b < p.B; ++b) tot += c[b];
     if (tot == 0 && alpha == 0.0) atomicOr(p.flag, 2);
     const double den = (double)tot + alpha * (double)p.B;
     double h = 0.0;
+#pragma unroll 4
     for (int b = 0; b < p.B; ++b) {
         const double P = ((double)c[b] + alpha) / den;
         const double LP = log(P);
@@ -217,15 +296,17 @@ __global__ void sum_layers_kernel(const double *__restrict__ Hpart, int nl, int6
 __global__ void prep_kl_sparse_kernel(PrepArgs p, double alpha, int symmetric, int nl, int half_cols /* padded columns of one half */,
                                       double *__restrict__ X, double *__restrict__ Y, double *__restrict__ Hpart /* [nl][npad] */,
                                       double *__restrict__ LZpart /* [nl][npad]: log Z */) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int kk = blockIdx.y;
     const int k = p.layer_lo + kk;
-    if (i >= p.n) return;
-    const uint32_t *c = p.counts + ((int64_t)i * p.L + k) * p.B;
+    int64_t i;
+    const uint32_t *c = counts_row(p, k, i);
+    if (!c) return;
     uint32_t tot = 0;
+    #pragma unroll 8
     for (int b = 0; b < p.B; ++b) tot += c[b];
     const double Z = (double)tot + alpha * (double)p.B, la = log(alpha);
     double h = 0.0, Ls = 0.0;
+#pragma unroll 4
     for (int b = 0; b < p.B; ++b) {
         const double lc = log((double)c[b] + alpha);
         const double P = ((double)c[b] + alpha) / Z;
@@ -316,9 +397,14 @@ __global__ void sort_counts_kernel(const uint32_t *__restrict__ in, uint32_t *__
 // per-column maximum of a uint32 bin-major matrix (one workgroup per column)
 __global__ __launch_bounds__(256) void colmax_u32_kernel(const uint32_t *__restrict__ X, int64_t npad, uint32_t *__restrict__ out) {
     __shared__ uint32_t red[256];
-    const uint32_t *col = X + (int64_t)blockIdx.x * npad;
+    // (npad is a multiple of 128 words and the matrix 16-byte aligned: 16-byte loads, four in flight per lane)
+    const uint4 *col = reinterpret_cast<const uint4 *>(X + (int64_t)blockIdx.x * npad);
     uint32_t m = 0;
-    for (int64_t i = threadIdx.x; i < npad; i += 256) m = max(m, col[i]);
+#pragma unroll 4
+    for (int64_t i = threadIdx.x; i < npad / 4; i += 256) {
+        const uint4 v = col[i];
+        m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
+    }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -337,11 +423,19 @@ __global__ void pack_u16_kernel(const uint32_t *__restrict__ X32, int64_t npad, 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int s = blockIdx.y;
     if (i >= npad || s >= n_seg) return;
+    // (a column that is not split has vdiv = vmul = 1 -- the usual case --: no 32-bit division, which is ~30 instructions on this machine; the
+    // choice is uniform over the wave)
+#pragma unroll 4
     for (int c = 0; 2 * c < V; ++c) {
         uint32_t w[2] = {0u, 0u};
+#pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int v = 2 * c + h;
-            if (v < V) w[h] = X32[((int64_t)s * stride32 + vsrc[v]) * npad + i] / vdiv[v] * vmul[v];
+            if (v < V) {
+                const uint32_t x = X32[((int64_t)s * stride32 + vsrc[v]) * npad + i];
+                const uint32_t d = vdiv[v], m = vmul[v];
+                w[h] = (d == 1u && m == 1u) ? x : x / d * m;
+            }
         }
         X16[((int64_t)s * stride16 + c) * npad + i] = w[0] | (w[1] << 16);
     }
@@ -357,7 +451,7 @@ int prepare_w1_raw(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, int n
     const size_t cnt = (size_t)std::max(ctx->dcols, CH) * p.npad;
     { const int rc_x = hsd_pool_alloc(ctx, &ctx->d_X, cnt * sizeof(double)); if (rc_x) return rc_x; }
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_X, 0, cnt * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(prep_l1_kernel, grid, block, 0, ctx->stream, p, (double *)ctx->d_X, 0, cpl, ctx->d_H);
+    { const PrepGeom g = prep_launch_geometry(p, (int)grid.y); hipLaunchKernelGGL(prep_l1_kernel, g.grid, g.block, g.lds, ctx->stream, p, (double *)ctx->d_X, 0, cpl, ctx->d_H); }
     ctx->mode = PAIR_L1_F64;
     ctx->n_seg = 0;
     ctx->l1_cols_per_layer = cpl;
@@ -408,10 +502,11 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
         // asynchronous copy would depend on; seg_begin lives in the context)
         hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)(((size_t)nsg * npad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_inv, (int64_t)nsg * npad, 2.0);
         HSD_HIP(ctx, hipMemcpyAsync(dseg.p, ctx->seg_begin, sizeof(ctx->seg_begin), hipMemcpyHostToDevice, ctx->stream));
+        const PrepGeom g = prep_launch_geometry(p, (int)grid.y);
         if (use_u32)
-            hipLaunchKernelGGL(prep_zp_kernel<uint32_t>, grid, block, 0, ctx->stream, p, x0.as<uint32_t>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
+            hipLaunchKernelGGL(prep_zp_kernel<uint32_t>, g.grid, g.block, g.lds, ctx->stream, p, x0.as<uint32_t>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
         else
-            hipLaunchKernelGGL(prep_zp_kernel<double>, grid, block, 0, ctx->stream, p, x0.as<double>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
+            hipLaunchKernelGGL(prep_zp_kernel<double>, g.grid, g.block, g.lds, ctx->stream, p, x0.as<double>(), ctx->d_inv, ctx->d_H, dseg.as<int>(), ntot.as<uint32_t>());
         HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     mark("support check + bin columns");
@@ -504,7 +599,8 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             HSD_TMP_ALLOC(ctx, dgm, (size_t)nl_hist * NC * ngran16 * sizeof(uint32_t));
             HSD_HIP(ctx, hipMemcpyAsync(dcand.p, cand.data(), (size_t)NC * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
             HSD_HIP(ctx, hipMemsetAsync(dabove.p, 0, (size_t)nl_hist * NC * npad * sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(count_above_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nl_hist), block, 0, ctx->stream, p, dcand.as<int>(), NC,
+            const PrepGeom g = prep_launch_geometry(p, nl_hist);
+            hipLaunchKernelGGL(count_above_kernel, g.grid, g.block, g.lds, ctx->stream, p, dcand.as<int>(), NC,
                                dabove.as<uint32_t>());
             hipLaunchKernelGGL(granule16_max_kernel, dim3((unsigned)((ngran16 + 255) / 256), (unsigned)(nl_hist * NC)), dim3(256), 0, ctx->stream,
                                dabove.as<uint32_t>(), npad, ngran16, dgm.as<uint32_t>());
@@ -538,34 +634,78 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             const bool may_sort = !(es && atoi(es) == 0) && G16 >= 16;
             const int64_t NT = std::max<int64_t>(1, G16 / 8);     // tiles of eight granules (a last, shorter group counts as one)
             std::vector<int32_t> order((size_t)G16);
-            auto plan_for = [&](const std::vector<int32_t> &ord, std::vector<LayerPlan> &plan) -> double {
-                double total = 0.0;
+            // Pricing one granule order = for every (layer, candidate threshold) the expected words over all unordered tile pairs.  The minimum of a pair
+            // is the smaller of its tiles' maxima, so with the tiles sorted by their word count the k-th smallest (0-based) is the minimum of nt - k pairs:
+            // the sum needs the COUNTS per word count only (every term is an integer: the result is the same number whatever the order of summation).
+            // gT: the granule maxima transposed to [granule][layer x candidate], so that one pass over an order's granules yields every combination's tile
+            // maxima at once (round 5: this pricing was 2.2 of 4.9 ms of a warm hsd_pair_prepare at BA N = 100k -- 24 orders x 24 combinations, each
+            // with its own gather and its own std::sort of 781 tile maxima).
+            const int ncomb = nl_hist * NC;
+            std::vector<int> low_of((size_t)NC), hi_of((size_t)NC), hi_comb((size_t)ncomb);
+            int hi_max = 0;
+            for (int q = 0; q < NC; ++q) {
+                low_of[(size_t)q] = vfirst[(size_t)cand[(size_t)q]] / (pack ? 2 : 1);
+                hi_of[(size_t)q] = bin_words - low_of[(size_t)q];
+                hi_max = std::max(hi_max, hi_of[(size_t)q]);
+            }
+            for (int c = 0; c < ncomb; ++c) hi_comb[(size_t)c] = hi_of[(size_t)(c % NC)];
+            const int NBK = hi_max + 1;                           // word counts 0 .. hi_w - 1, and one bucket for "hi_w or more" (never fits the cap)
+            // A maximum enters the price only through min(words_of(.), hi_w): values are clamped to the smallest one whose word count reaches every
+            // hi_w, which makes the table 16-bit (signed: the host's baseline vector max) whenever the bin form has fewer than 16 k words
+            const int64_t clamp_to = pack ? 2 * (int64_t)hi_max : (int64_t)hi_max;
+            const bool narrow = clamp_to <= 32767;
+            std::vector<int16_t> gT16;
+            std::vector<uint32_t> gT32;
+            if (narrow) gT16.resize((size_t)(G16 + 1) * ncomb, 0); else gT32.resize((size_t)(G16 + 1) * ncomb, 0u);
+            for (int c = 0; c < ncomb; ++c) {
+                const uint32_t *gm = gmax16.data() + (size_t)c * ngran16;
+                for (int64_t g = 0; g <= G16 && g < ngran16; ++g) {
+                    if (narrow) gT16[(size_t)g * ncomb + c] = (int16_t)std::min<int64_t>((int64_t)gm[g], clamp_to);
+                    else gT32[(size_t)g * ncomb + c] = gm[g];
+                }
+            }
+            auto plan_with = [&](const auto *gT, const std::vector<int32_t> &ord, std::vector<LayerPlan> &plan) -> double {
+                using E = std::remove_cv_t<std::remove_reference_t<decltype(gT[0])>>;
                 const int64_t nt = (G16 + 7) / 8;
-                std::vector<uint32_t> tm((size_t)nt);             // (per call: candidate orders are evaluated on several host threads)
+                std::vector<E> tm((size_t)ncomb), gmx((size_t)ncomb, (E)0);            // (per call: candidate orders are evaluated on several host threads)
+                std::vector<int32_t> cnt((size_t)ncomb * NBK, 0);
+                E *const tmp = tm.data(), *const gmp = gmx.data();
+                for (int64_t t = 0; t < nt; ++t) {
+                    for (int c = 0; c < ncomb; ++c) tmp[c] = (E)0;
+                    for (int64_t e = 8 * t; e < std::min<int64_t>(G16, 8 * t + 8); ++e) {
+                        const E *row = gT + (size_t)ord[(size_t)e] * ncomb;
+                        for (int c = 0; c < ncomb; ++c) tmp[c] = std::max(tmp[c], row[c]);
+                    }
+                    for (int c = 0; c < ncomb; ++c) gmp[c] = std::max(gmp[c], tmp[c]);
+                    for (int c = 0; c < ncomb; ++c) {
+                        const int hi_w = hi_comb[(size_t)c];
+                        if (hi_w < 2) continue;
+                        const int64_t wr = words_of((uint32_t)tmp[c]);
+                        ++cnt[(size_t)c * NBK + (size_t)std::min<int64_t>(wr, hi_w)];
+                    }
+                }
+                double total = 0.0;
                 for (int sgi = 0; sgi < nl_hist; ++sgi) {
                     LayerPlan bp{-1, 0, 0.97 * bin_words};
                     for (int q = 0; q < NC; ++q) {
-                        const int low_w = vfirst[(size_t)cand[(size_t)q]] / (pack ? 2 : 1), hi_w = bin_words - low_w;
+                        const int c = sgi * NC + q;
+                        const int low_w = low_of[(size_t)q], hi_w = hi_of[(size_t)q];
                         if (hi_w < 2) continue;
-                        const uint32_t *gm = gmax16.data() + ((size_t)sgi * NC + q) * ngran16;
-                        uint32_t gmx = 0;
-                        for (int64_t t = 0; t < nt; ++t) {
-                            uint32_t m = 0;
-                            for (int64_t e = 8 * t; e < std::min<int64_t>(G16, 8 * t + 8); ++e) m = std::max(m, gm[ord[(size_t)e]]);
-                            tm[(size_t)t] = m;
-                            gmx = std::max(gmx, m);
-                        }
-                        if (n % 16) gmx = std::max(gmx, gm[G16]);        // (the partial last granule: one-tile kernel only)
-                        std::sort(tm.begin(), tm.begin() + nt);
-                        const int cap = (int)std::min<int64_t>(hi_w - 1, words_of(gmx));
-                        // E over unordered tile pairs of f(min): the k-th smallest (0-based) is the minimum of nt - k pairs
-                        long double acc = 0.0L;
-                        for (int64_t k2 = 0; k2 < nt; ++k2) {
-                            int64_t wr = words_of(tm[(size_t)k2]);
+                        uint32_t g_all = (uint32_t)gmx[(size_t)c];
+                        if (n % 16) g_all = std::max(g_all, (uint32_t)gT[(size_t)G16 * ncomb + c]);        // (the partial last granule: one-tile kernel only)
+                        const int cap = (int)std::min<int64_t>(hi_w - 1, words_of(g_all));
+                        // sum over the tiles in ascending order of f(words) x (nt - position): a bucket of c_b tiles at positions k0 .. k0 + c_b - 1
+                        int64_t acc = 0, k0 = 0;
+                        for (int b = 0; b <= hi_w; ++b) {
+                            const int64_t cb = cnt[(size_t)c * NBK + b];
+                            if (!cb) continue;
+                            int64_t wr = b;
                             if (low_w + wr == 0) wr = 1;
-                            acc += (long double)(wr <= cap ? wr : hi_w) * (long double)(nt - k2);
+                            const int64_t f = (b < hi_w && wr <= cap) ? wr : hi_w;
+                            acc += f * (cb * nt - (cb * k0 + cb * (cb - 1) / 2));
+                            k0 += cb;
                         }
-                        const double cost = low_w + (double)(acc / ((long double)nt * (nt + 1) / 2));
+                        const double cost = low_w + (double)((long double)acc / ((long double)nt * (nt + 1) / 2));
                         if (cost < bp.cost) bp = LayerPlan{q, cap, cost};
                     }
                     if (bp.q < 0) bp.cost = bin_words;
@@ -573,6 +713,9 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                     total += bp.cost;
                 }
                 return total;
+            };
+            auto plan_for = [&](const std::vector<int32_t> &ord, std::vector<LayerPlan> &plan) -> double {
+                return narrow ? plan_with(gT16.data(), ord, plan) : plan_with(gT32.data(), ord, plan);
             };
             (void)NT;
             for (int64_t g = 0; g < G16; ++g) order[(size_t)g] = (int32_t)g;
@@ -589,7 +732,7 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                 std::vector<std::vector<LayerPlan>> t_plan((size_t)n_task, std::vector<LayerPlan>((size_t)nl_hist));
                 std::vector<double> t_total((size_t)n_task, 0.0);
                 const char *ept = hsd_hook(H_PLAN_THREADS);    // cap of the host threads (1: everything on the calling thread)
-                int thr_cap = ept ? atoi(ept) : 16;
+                int thr_cap = ept ? atoi(ept) : 4;              // (round 5: a task is ~35 us now; more threads cost more to start than they save)
                 if (thr_cap < 1) thr_cap = 1;
                 const int n_thr = std::max(1, std::min<int>(std::min(n_task, thr_cap), std::max(1, (int)std::thread::hardware_concurrency())));
                 // tasks are drawn from a shared counter, so whatever threads exist (possibly none but the caller) finish them all
@@ -601,8 +744,18 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
                             const uint32_t *key = gmax16.data() + (size_t)task * ngran16;        // task = ks * NC + kq
                             std::vector<int32_t> &ord = t_order[(size_t)task];
                             ord.resize((size_t)G16);
-                            for (int64_t g = 0; g < G16; ++g) ord[(size_t)g] = (int32_t)g;
-                            std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+                            // stable order by key: a counting sort where the keys are small (member counts), std::stable_sort otherwise -- the same permutation
+                            uint32_t kmax = 0;
+                            for (int64_t g = 0; g < G16; ++g) kmax = std::max(kmax, key[g]);
+                            if (kmax < (1u << 20)) {
+                                std::vector<int32_t> at((size_t)kmax + 2, 0);
+                                for (int64_t g = 0; g < G16; ++g) ++at[(size_t)key[g] + 1];
+                                for (size_t v = 1; v < at.size(); ++v) at[v] += at[v - 1];
+                                for (int64_t g = 0; g < G16; ++g) ord[(size_t)at[(size_t)key[g]]++] = (int32_t)g;
+                            } else {
+                                for (int64_t g = 0; g < G16; ++g) ord[(size_t)g] = (int32_t)g;
+                                std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+                            }
                             t_total[(size_t)task] = plan_for(ord, t_plan[(size_t)task]);
                         }
                     } catch (...) { task_failed.store(true); }
@@ -714,9 +867,9 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             }
             HSD_TMP_ALLOC(ctx, dr, rc0.size() * sizeof(int));
             HSD_HIP(ctx, hipMemcpyAsync(dr.p, rc0.data(), rc0.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            const dim3 rgrid((unsigned)((n + 255) / 256), (unsigned)nl_hist);
-            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
-            else hipLaunchKernelGGL(prep_rank_kernel<false>, rgrid, block, 0, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
+            const PrepGeom g = prep_launch_geometry(p, nl_hist);
+            if (pack) hipLaunchKernelGGL(prep_rank_kernel<true>, g.grid, g.block, g.lds, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
+            else hipLaunchKernelGGL(prep_rank_kernel<false>, g.grid, g.block, g.lds, ctx->stream, p, dr.as<int>(), dr.as<int>() + nl_hist, dr.as<int>() + 2 * nl_hist, dr.as<int>() + 3 * nl_hist, (uint32_t *)ctx->d_X, ctx->d_suf);
             HSD_HIP(ctx, hipStreamSynchronize(ctx->stream));      // dr leaves scope
         }
         mark("rank columns + suffix sums");
@@ -758,22 +911,34 @@ int prepare_w1_zeropad(hsd_ctx *ctx, const PrepArgs &p, dim3 grid, dim3 block, i
             cr.push_back(cap);
             double best_save = 0.0;
             int best_b = -1, best_r = -1;
-            std::vector<int64_t> wrs;
+            // the tiles once in ascending order of their rank words; every (b8, r16) then walks the qualifying ones in that order (the sum's terms are
+            // integers: equal word counts may come in any order)
+            std::vector<int32_t> by_words((size_t)nt);
+            for (int64_t t = 0; t < nt; ++t) by_words[(size_t)t] = (int32_t)t;
+            std::stable_sort(by_words.begin(), by_words.end(), [&](int32_t x, int32_t y) { return tR[(size_t)x] < tR[(size_t)y]; });
+            std::vector<int32_t> sb8((size_t)nt), sr8((size_t)nt);
+            std::vector<int64_t> swr((size_t)nt);
+            for (int64_t k2 = 0; k2 < nt; ++k2) {
+                const size_t t = (size_t)by_words[(size_t)k2];
+                sb8[(size_t)k2] = (int32_t)std::min<uint32_t>(tb8[t], 0x7fffffffu);
+                sr8[(size_t)k2] = (int32_t)std::min<uint32_t>(tr8[t], 0x7fffffffu);
+                swr[(size_t)k2] = words_of(tR[t]);
+            }
             for (int b8 : cb)
                 for (int r16 : cr) {
                     const int fixed = b8 + r16 + (low - b8 + 1) / 2;
-                    wrs.clear();
-                    for (int64_t t = 0; t < nt; ++t)
-                        if ((int)tb8[(size_t)t] <= b8 && (int)tr8[(size_t)t] <= r16) wrs.push_back(words_of(tR[(size_t)t]));
-                    std::sort(wrs.begin(), wrs.end());
+                    int64_t m = 0;
+                    for (int64_t t = 0; t < nt; ++t) m += (int)(sb8[(size_t)t] <= b8) & (int)(sr8[(size_t)t] <= r16);
                     long double save = 0.0L;
-                    const int64_t m = (int64_t)wrs.size();
-                    for (int64_t k2 = 0; k2 < m; ++k2) {
-                        int64_t wr = wrs[(size_t)k2];
+                    int64_t k2 = 0;
+                    for (int64_t t = 0; t < nt && k2 < m; ++t) {
+                        if (!(sb8[(size_t)t] <= b8 && sr8[(size_t)t] <= r16)) continue;
+                        int64_t wr = swr[(size_t)t];
                         if (low + wr == 0) wr = 1;
                         if (wr > cap) break;
                         const int64_t c16 = low + wr, c8 = fixed + std::max<int64_t>(wr - r16, 0) / 2 + (std::max<int64_t>(wr - r16, 0) & 1);
                         if (c8 >= 1 && c8 < c16) save += (long double)(c16 - c8) * (long double)(m - k2);
+                        ++k2;
                     }
                     const double sv = (double)(save / ((long double)nt * (nt + 1) / 2));
                     if (sv > best_save) { best_save = sv; best_b = b8; best_r = r16; }
@@ -824,6 +989,7 @@ __global__ void kl_point_kernel(PrepArgs p, double *__restrict__ point) {
     if (i >= p.n) return;
     const uint32_t *c = p.counts + (int64_t)i * p.L * p.B;
     uint32_t tot = 0;
+    #pragma unroll 8
     for (int b = 0; b < p.B; ++b) tot += c[b];
     const int nb = p.node_bin[i];
     if (tot != 1u || c[nb] != 1u) atomicOr(p.flag + 1, 4);
@@ -889,12 +1055,14 @@ int prepare_kl(hsd_ctx *ctx, PrepArgs p, dim3 grid, dim3 block, int nl, int metr
         p.counts = sorted.as<uint32_t>();
     }
     if (!sparse) {
-        hipLaunchKernelGGL(prep_kl_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
+        const PrepGeom g = prep_launch_geometry(p, (int)grid.y);
+        hipLaunchKernelGGL(prep_kl_kernel, g.grid, g.block, g.lds, ctx->stream, p, kl_alpha, sym, half, (double *)ctx->d_X,
                            (double *)ctx->d_Y, hpart.as<double>());
     } else {
         DevTmp lz;
         HSD_TMP_ALLOC(ctx, lz, (size_t)nl * npad * sizeof(double));
-        hipLaunchKernelGGL(prep_kl_sparse_kernel, grid, block, 0, ctx->stream, p, kl_alpha, sym, nl, half, (double *)ctx->d_X, (double *)ctx->d_Y,
+        const PrepGeom g = prep_launch_geometry(p, (int)grid.y);
+        hipLaunchKernelGGL(prep_kl_sparse_kernel, g.grid, g.block, g.lds, ctx->stream, p, kl_alpha, sym, nl, half, (double *)ctx->d_X, (double *)ctx->d_Y,
                            hpart.as<double>(), lz.as<double>());
         hipLaunchKernelGGL(kl_logz_column_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, ctx->stream, (const double *)lz.as<double>(), nl, npad, n,
                            (int64_t)nl * B + nl, sym, half, (double *)ctx->d_X, (double *)ctx->d_Y);
@@ -931,7 +1099,15 @@ int pair_prepare_impl(hsd_ctx *ctx, int metric, int align, int layer_lo, int lay
     ctx->npad = npad;
     ctx->list_cap = 0;
     HSD_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, 4 * sizeof(int), ctx->stream));
-    PrepArgs p{ctx->d_counts, ctx->d_support, ctx->d_node_bin, n, npad, L, B, layer_lo, layer_hi, ctx->d_flag};
+    // rows staged through LDS where 64 (32, 16) of them fit 64 KiB (HSD_PREP_STAGED=0: never)
+    int stage_nodes = 0;
+    {
+        const char *es = hsd_hook(H_PREP_STAGED);
+        if (!(es && atoi(es) == 0))
+            for (int c : {64, 32, 16})
+                if ((size_t)c * (size_t)(B | 1) * sizeof(uint32_t) <= (size_t)64 * 1024) { stage_nodes = c; break; }
+    }
+    PrepArgs p{ctx->d_counts, ctx->d_support, ctx->d_node_bin, n, npad, L, B, layer_lo, layer_hi, ctx->d_flag, stage_nodes};
     const int nl = layer_hi - layer_lo + 1;
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nl), block(256);
     int rc;

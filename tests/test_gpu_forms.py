@@ -210,6 +210,26 @@ def test_plan_does_not_depend_on_host_threads(engine, capfd):
         assert np.array_equal(seen[tag][2], seen["default"][2])
 
 
+@pytest.mark.parametrize("n", [777, 5003])
+def test_operand_preparation_staged_rows_equal_in_place_rows(engine, n):
+    """The operand-preparation kernels walk every node's histogram row; by default workgroups stage the rows of 64 (32, 16) consecutive nodes in LDS
+    with coalesced loads first (csrc/pair_prepare.hip: counts_row), HSD_PREP_STAGED=0 reads each row in place.  Same operands: every distance kind's
+    matrix rows are bit-identical, for a node count that is not a multiple of the stage (the last workgroup holds fewer nodes)."""
+    g = _scale_free(n, seed=11)
+    engine.set_graph(g.rowptr, g.col)
+    engine.signature_build_degree(3)
+    r0, r1 = 0, min(n, 640)
+    kinds = [(0, 1, 0, 2, 0.5, False), (0, 0, 0, 3, 0.5, False), (0, 1, 1, 3, 0.5, False), (1, 0, 0, 3, 0.5, False), (2, 0, 0, 3, 0.25, False), (1, 0, 0, 3, 0.5, True)]
+    for kind in kinds:
+        rows = {}
+        for staged in ("1", "0"):
+            with _Env(HSD_PREP_STAGED=staged):
+                engine.pair_prepare(*kind)
+            rows[staged] = (engine.pair_rows_host(r0, r1), engine.pair_operand_dims())
+        assert rows["1"][1] == rows["0"][1], kind
+        assert np.array_equal(rows["1"][0], rows["0"][0]), (kind, np.abs(rows["1"][0] - rows["0"][0]).max())
+
+
 def test_persistent_kernel_corner_shapes(engine):
     """Forced persistent kernel on shapes its size heuristic would not pick: a distance with NO histogram layer (K = 1,
     layers 0..0: tiles without operand chunks, only the ring-0 term), and a hierarchy too deep for its LDS budget
